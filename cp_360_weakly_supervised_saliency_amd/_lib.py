@@ -1,0 +1,116 @@
+"""ctypes binding of csrc/libcp360.so (the C ABI declared in include/cp360.h).
+
+No CPU fallback: ``lib()`` raises if the shared library has not been built
+(``make -C cp_360_weakly_supervised_saliency_amd/csrc`` or
+``__graft_entry__.build()``), and every op checks that its tensors live on a GPU.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libcp360.so')
+
+F32, BF16, U8 = 0, 1, 3
+OK = 0
+
+# every exported symbol of include/cp360.h (checked by tests/test_abi.py)
+SYMBOLS = [
+    'cp360_strerror', 'cp360_version', 'cp360_cubepad_table_host', 'cp360_cubepad_nchw',
+    'cp360_cubepad_nhwc', 'cp360_nchw_to_nhwc', 'cp360_nhwc_to_nchw', 'cp360_equi2cube',
+    'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes',
+    'cp360_conv_pack_weights', 'cp360_conv_forward', 'cp360_conv_finish',
+    'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_window_minmax',
+    'cp360_window_normalize',
+]
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``cp360_conv_desc`` (include/cp360.h)."""
+    _fields_ = [(n, C.c_int) for n in (
+        'dtype', 'n_img', 'h_in', 'w_in', 'c_in', 'pix_stride', 'kh', 'kw', 'sy', 'sx',
+        'h_out', 'w_out', 'c_out', 'pad_mode', 'pad', 'ld_out', 'out_coff', 'ld_res',
+        'relu', 'splits')]
+
+
+class Cp360Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libcp360.so not found at %s - the HIP library must be built "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    pd = C.POINTER(ConvDesc)
+    L.cp360_strerror.restype = C.c_char_p
+    L.cp360_strerror.argtypes = [i]
+    L.cp360_version.restype = i
+    L.cp360_cubepad_table_host.argtypes = [i, i, i, i, i, vp]
+    L.cp360_cubepad_nchw.argtypes = [vp, vp, i, i, i, i, i, i, i, i, vp]
+    L.cp360_cubepad_nhwc.argtypes = [vp, vp, i, i, i, i, i, i, i, i, i, vp]
+    L.cp360_nchw_to_nhwc.argtypes = [vp, vp, i, i, i, i, i, i, i, i, vp]
+    L.cp360_nhwc_to_nchw.argtypes = [vp, vp, i, i, i, i, i, i, i, i, vp]
+    L.cp360_equi2cube.argtypes = [vp, vp, vp, i, i, i, i, C.POINTER(f), C.POINTER(f), f, i, i, i, i, vp]
+    L.cp360_cube2equi.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+    L.cp360_conv_packed_bytes.restype = sz
+    L.cp360_conv_packed_bytes.argtypes = [pd]
+    L.cp360_conv_partial_bytes.restype = sz
+    L.cp360_conv_partial_bytes.argtypes = [pd]
+    L.cp360_conv_pack_weights.argtypes = [pd, vp, vp, vp, i, vp]
+    L.cp360_conv_forward.argtypes = [pd, vp, vp, vp, vp, vp, vp, vp]
+    L.cp360_conv_finish.argtypes = [pd, vp, vp, vp, vp, vp]
+    L.cp360_cubepad_maxpool3s2.argtypes = [vp, vp, i, i, i, i, vp]
+    L.cp360_lstm_gates.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, vp]
+    L.cp360_window_minmax.argtypes = [vp, vp, vp, i, sz, vp]
+    L.cp360_window_normalize.argtypes = [vp, vp, vp, i, i, i, vp, i, i, i, i, i, vp]
+    for name in SYMBOLS:
+        getattr(L, name)          # AttributeError here = header and library disagree
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        msg = lib().cp360_strerror(int(status)).decode()
+        if status in (-1, -2, -3, -4, -6):
+            raise ValueError("cp360: %s (status %d)" % (msg, status))
+        raise Cp360Error("cp360: %s (status %d)" % (msg, status))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    """The HIP stream torch is currently queueing on (the library is stream-ordered)."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cp360 ops run on the GPU only (HIP); got a %s tensor - there is no CPU fallback"
+                               % t.device)
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.uint8:
+        return U8
+    raise ValueError("unsupported dtype %s" % dt)

@@ -1,0 +1,519 @@
+// K3 / K4 / K5: implicit-GEMM convolution on MFMA for gfx950.
+//
+//   out[m, n] = act( sum_{tap, c} W[n, tap, c] * in[src(m, tap), c] + bias[n] (+ res[m, n]) )
+//
+// m = (image, oy, ox) output pixel, n = output channel, NHWC activations, weights
+// pre-packed [c_out_pad][tap][c_pad] (K contiguous).  Replaces nn.Conv2d + folded
+// BatchNorm2d + ReLU + residual of model/resnet_cubic.py:85-106,163-175, the CAM GEMM of
+// static_model/class_activation_model.py:70-83 and the 3x3 convs of model/clstm.py:56-64.
+// The CubePad(p) in front of every 3x3 conv (cube_pad.py:95-216) is NOT materialised:
+// src(m, tap) goes through cubepad_src() while the activation tile is gathered.
+//
+// Tiling (wave64, MFMA 16x16):
+//   workgroup = 4 waves, tile = (WN*64 output channels) x (WM*64 pixels), wave tile 64x64
+//   = 4x4 MFMA tiles, f32 accumulators (64 VGPRs).  MFMA "A" operand = weights (rows =
+//   output channels), "B" operand = activations (columns = pixels), so a lane ends up
+//   with 4 consecutive output channels of one pixel -> 16-byte NHWC stores.
+//   K step = 128 bytes per tile row (64 bf16 / 32 f32): every tile row in LDS is one
+//   128-byte line of eight 16-byte chunks, chunk c of row r stored at chunk
+//   c ^ ((r >> 1) & 7).  A 16-lane ds_read_b128 group (rows r0..r0+15, one logical
+//   chunk) then touches 16 distinct 16-byte slots of the 256-byte bank row:
+//   conflict-free reads, and the 8 lanes that write one row hit 8 distinct slots.
+//   Global -> register -> LDS staging, double-buffered LDS, one barrier per K step;
+//   the next step's global loads are in flight while the MFMAs of the current step run.
+//   f32 path: v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate; a lane's
+//   16-byte chunk feeds 4 consecutive MFMAs with k = 4*(lane>>4) + e).
+//   bf16 path: v_mfma_f32_16x16x32_bf16 (a lane's 16-byte chunk = its 8 k-values).
+//   Split-K (gridDim.z) writes f32 partial slabs; conv_finish / lstm_gates reduce them.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+struct ConvK {
+    const unsigned char* in;
+    const unsigned char* w;
+    unsigned char* out;
+    const float* bias;
+    const unsigned char* res;
+    float* partial;
+    int n_img, h_in, w_in, c_in, pix_stride, kh, kw, sy, sx, h_out, w_out, c_out;
+    int pad_mode, pad, ld_out, out_coff, ld_res, relu, splits;
+    int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPC = 4; };      // elements per 16-byte chunk
+template <> struct Elem<bf16_raw> { static constexpr int EPC = 8; };
+
+__device__ __forceinline__ int lds_swz(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b);
+
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<bf16_raw>(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
+                                                  0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
+template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_as_f32<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
+
+// store 4 consecutive channels
+__device__ __forceinline__ void store4(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_raw* p, const float v[4]) {
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = o;
+}
+__device__ __forceinline__ void load4(const float* p, float v[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+template <typename T, int WN, int WM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+    constexpr int BN = WN * 64, BM = WM * 64;
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int A_PASSES = BN / 32, B_PASSES = BM / 32;
+    constexpr int STAGE = (BN + BM) * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, split = blockIdx.z;
+    const int chunk = tid & 7, row0 = tid >> 3;
+
+    // ---- per-thread activation rows: decode (image, oy*sy, ox*sx) once
+    int rimg[B_PASSES], rpos[B_PASSES], roff[B_PASSES];
+#pragma unroll
+    for (int pb = 0; pb < B_PASSES; ++pb) {
+        const int m = m0 + row0 + 32 * pb;
+        if (m < p.M) {
+            const int img = m / p.hw_out, rem = m - img * p.hw_out;
+            const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+            rimg[pb] = img;
+            rpos[pb] = ((oy * p.sy) << 16) | (ox * p.sx);
+        } else {
+            rimg[pb] = -1;
+            rpos[pb] = 0;
+        }
+        roff[pb] = -1;
+    }
+    const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
+    auto set_tap = [&](int tap) {
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb) {
+            if (rimg[pb] >= 0) {
+                const int py = (rpos[pb] >> 16) + ky, px = (rpos[pb] & 0xffff) + kx;
+                int pix;
+                if (p.pad_mode) {
+                    const int grp = rimg[pb] / 6, f = rimg[pb] - grp * 6;
+                    pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
+                } else {
+                    pix = (rimg[pb] * p.h_in + py) * p.w_in + px;
+                }
+                roff[pb] = pix * p.pix_stride;
+            }
+        }
+    };
+
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    int tap = s_begin / p.steps_per_tap;
+    int c0 = (s_begin - tap * p.steps_per_tap) * BK;
+
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wrow[A_PASSES];
+#pragma unroll
+    for (int pa = 0; pa < A_PASSES; ++pa)
+        wrow[pa] = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + row0 + 32 * pa) * p.k_total + chunk * EPC;
+
+    uint4 ra[A_PASSES], rb[B_PASSES];
+    auto gload = [&]() {
+        const int e = c0 + chunk * EPC;
+        const size_t koff = (size_t)tap * p.c_pad + c0;
+#pragma unroll
+        for (int pa = 0; pa < A_PASSES; ++pa) ra[pa] = *reinterpret_cast<const uint4*>(wrow[pa] + koff);
+        // unconditional loads (invalid rows / K tail read element 0 and are zeroed by a
+        // select): no exec-mask branches in the K loop
+        const bool kval = e < p.c_in;
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb) {
+            const bool ok = kval && roff[pb] >= 0;
+            const uint4 t = *reinterpret_cast<const uint4*>(in + (ok ? (size_t)roff[pb] + e : (size_t)0));
+            rb[pb] = ok ? t : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lds_store = [&](int buf) {
+        unsigned char* As = lds + buf * STAGE;
+        unsigned char* Bs = As + BN * 128;
+#pragma unroll
+        for (int pa = 0; pa < A_PASSES; ++pa)
+            *reinterpret_cast<uint4*>(As + lds_swz(row0 + 32 * pa, chunk)) = ra[pa];
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb)
+            *reinterpret_cast<uint4*>(Bs + lds_swz(row0 + 32 * pb, chunk)) = rb[pb];
+    };
+    auto advance = [&]() {
+        c0 += BK;
+        if (c0 >= p.c_pad) {
+            c0 = 0;
+            ++tap;
+            set_tap(tap);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (s_begin < s_end) {
+        set_tap(tap);
+        gload();
+        lds_store(0);
+        __syncthreads();
+        const int lrow = lane & 15, lchunk = lane >> 4;
+        for (int s = s_begin; s < s_end; ++s) {
+            const int buf = (s - s_begin) & 1;
+            const bool more = (s + 1) < s_end;
+            if (more) {
+                advance();
+                gload();
+            }
+            const unsigned char* As = lds + buf * STAGE;
+            const unsigned char* Bs = As + BN * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const uint4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b[j] = *reinterpret_cast<const uint4*>(Bs + lds_swz(wm * 64 + j * 16 + lrow, kk * 4 + lchunk));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
+            }
+            if (more) lds_store(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds channels n..n+3 of pixel m for every (i, j) sub-tile
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + nl;
+        if (n >= p.c_out) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + ml;
+            if (m >= p.M) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.partial) {
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+            } else {
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (p.res) {
+                    float r[4];
+                    load4(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ld_res + n, r);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                store4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ld_out + p.out_coff + n, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ split-K finish
+template <typename T>
+__global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ partial, int splits,
+                                                          const float* __restrict__ bias, const T* __restrict__ res,
+                                                          int ld_res, T* __restrict__ out, int ld_out, int out_coff,
+                                                          int M, int c_out, int relu) {
+    const int q = c_out >> 2;
+    const long long total = (long long)M * q;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / q), n = (int)(idx - (long long)m * q) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(partial + ((size_t)s * M + m) * c_out + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+            v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (res) {
+            float r[4];
+            load4(res + (size_t)m * ld_res + n, r);
+            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+        }
+        if (relu) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        store4(out + (size_t)m * ld_out + out_coff + n, v);
+    }
+}
+
+// ------------------------------------------------------------------ ConvLSTM gate epilogue
+// model/clstm.py:68-80: gates = [in | remember | out | cell] chunks of Hc channels.
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict__ gp, int splits,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ c_prev, float* __restrict__ c_next,
+                                                         T* __restrict__ h_out, int ld_h, int h_coff,
+                                                         float* __restrict__ h_f32, int M, int Hc) {
+    const int q = Hc >> 2, G = 4 * Hc;
+    const long long total = (long long)M * q;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / q), j = (int)(idx - (long long)m * q) * 4;
+        float g[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + k * Hc + j);
+            g[k][0] = bb.x; g[k][1] = bb.y; g[k][2] = bb.z; g[k][3] = bb.w;
+        }
+        for (int s = 0; s < splits; ++s) {
+            const float* base = gp + ((size_t)s * M + m) * G + j;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(base + k * Hc);
+                g[k][0] += t.x; g[k][1] += t.y; g[k][2] += t.z; g[k][3] += t.w;
+            }
+        }
+        const float4 cp = *reinterpret_cast<const float4*>(c_prev + (size_t)m * Hc + j);
+        const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+        float cn[4], hn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ig = sigmoidf_(g[0][e]), fg = sigmoidf_(g[1][e]), og = sigmoidf_(g[2][e]);
+            const float cg = tanhf(g[3][e]);
+            cn[e] = fg * cpv[e] + ig * cg;
+            hn[e] = og * tanhf(cn[e]);
+        }
+        *reinterpret_cast<float4*>(c_next + (size_t)m * Hc + j) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+        store4(h_out + (size_t)m * ld_h + h_coff + j, hn);
+        if (h_f32) *reinterpret_cast<float4*>(h_f32 + (size_t)m * Hc + j) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    }
+}
+
+// ------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                           T* __restrict__ packed, int c_out, int c_out_pad, int c_in,
+                                                           int c_pad, int kh, int kw, int stem_mode) {
+    const int taps = kh * kw;
+    const long long total = (long long)c_out_pad * taps * c_pad;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c_pad);
+        const long long t = idx / c_pad;
+        const int tap = (int)(t % taps), n = (int)(t / taps);
+        float v = 0.f;
+        if (n < c_out) {
+            if (stem_mode) {   // desc kh=7, kw=1, c_in=32: k = kx*4 + ch of a [c_out,3,7,7] filter
+                const int kx = c >> 2, ch = c & 3, ky = tap;
+                if (c < c_in && kx < 7 && ch < 3) v = w[(((size_t)n * 3 + ch) * 7 + ky) * 7 + kx];
+            } else if (c < c_in) {
+                const int ky = tap / kw, kx = tap - ky * kw;
+                v = w[(((size_t)n * c_in + c) * kh + ky) * kw + kx];
+            }
+            if (scale) v *= scale[n];
+        }
+        if constexpr (sizeof(T) == 4)
+            packed[idx] = v;
+        else
+            packed[idx] = f32_to_bf16(v);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int elem_bytes(int dtype) { return dtype == CP360_F32 ? 4 : (dtype == CP360_BF16 ? 2 : 0); }
+static int bk_of(int dtype) { return 128 / elem_bytes(dtype); }
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+static int check_desc(const cp360_conv_desc* d) {
+    if (!d) return CP360_ERR_NULL;
+    if (d->dtype != CP360_F32 && d->dtype != CP360_BF16) return CP360_ERR_BAD_DTYPE;
+    if (d->n_img <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c_in <= 0 || d->kh <= 0 || d->kw <= 0 || d->sy <= 0 ||
+        d->sx <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_out <= 0 || d->splits < 1 || d->pix_stride <= 0)
+        return CP360_ERR_BAD_SHAPE;
+    const int epc = 16 / elem_bytes(d->dtype);
+    if (d->c_in % epc != 0 || d->c_out % 4 != 0 || d->ld_out % 4 != 0 || d->out_coff % 4 != 0 || d->ld_res % 4 != 0)
+        return CP360_ERR_ALIGN;
+    if (d->ld_out < d->c_out + d->out_coff) return CP360_ERR_BAD_SHAPE;
+    if (d->pad_mode) {
+        if (d->n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+        if (d->h_in != d->w_in) return CP360_ERR_NOT_SQUARE;
+        if (d->pad < 0 || d->pad > d->h_in) return CP360_ERR_BAD_SHAPE;
+    }
+    const int pad2 = d->pad_mode ? 2 * d->pad : 0;
+    if ((d->h_out - 1) * d->sy + d->kh > d->h_in + pad2) return CP360_ERR_BAD_SHAPE;
+    // pix_stride < c_in is the stem form: one tap reads c_in/pix_stride neighbouring pixels
+    const int span = d->pix_stride >= d->c_in ? 1 : (d->c_in + d->pix_stride - 1) / d->pix_stride;
+    if (span > 1 && d->pad_mode) return CP360_ERR_UNSUPPORTED;
+    if ((d->w_out - 1) * d->sx + (d->kw - 1) + span > d->w_in + pad2) return CP360_ERR_BAD_SHAPE;
+    if ((long long)d->n_img * d->h_in * d->w_in * d->pix_stride >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    return CP360_OK;
+}
+
+extern "C" size_t cp360_conv_packed_bytes(const cp360_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    const int c_pad = round_up(d->c_in, bk_of(d->dtype));
+    return (size_t)round_up(d->c_out, 128) * d->kh * d->kw * c_pad * elem_bytes(d->dtype);
+}
+
+extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
+    if (check_desc(d) || d->splits <= 1) return 0;
+    return (size_t)d->splits * d->n_img * d->h_out * d->w_out * d->c_out * sizeof(float);
+}
+
+extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const float* scale, void* packed,
+                                       int stem_mode, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w_oihw || !packed) return CP360_ERR_NULL;
+    if (stem_mode && !(d->kh == 7 && d->kw == 1 && d->c_in == 32)) return CP360_ERR_UNSUPPORTED;
+    const int c_pad = round_up(d->c_in, bk_of(d->dtype));
+    const int c_out_pad = round_up(d->c_out, 128);
+    const long long total = (long long)c_out_pad * d->kh * d->kw * c_pad;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CP360_F32)
+        hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
+                           (float*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
+    else
+        hipLaunchKernelGGL((pack_weights_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
+                           (bf16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+template <typename T, int WN, int WM>
+static void launch_conv(const ConvK& k, hipStream_t st) {
+    dim3 grid((k.c_out + WN * 64 - 1) / (WN * 64), (k.M + WM * 64 - 1) / (WM * 64), k.splits);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, WN, WM>), grid, dim3(256), 0, st, k);
+}
+
+extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, const void* packed_w, const float* bias,
+                                  const void* residual, void* out, float* partial, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!in || !packed_w) return CP360_ERR_NULL;
+    if (d->splits > 1 && !partial) return CP360_ERR_NULL;
+    if (d->splits == 1 && !out && !partial) return CP360_ERR_NULL;
+    if (residual && d->ld_res < d->c_out) return CP360_ERR_BAD_SHAPE;
+    ConvK k;
+    k.in = (const unsigned char*)in;
+    k.w = (const unsigned char*)packed_w;
+    k.out = (unsigned char*)out;
+    k.bias = bias;
+    k.res = (const unsigned char*)residual;
+    k.partial = (d->splits > 1 || !out) ? partial : nullptr;   // out == NULL: raw f32 sums [splits, M, c_out]
+    k.n_img = d->n_img; k.h_in = d->h_in; k.w_in = d->w_in; k.c_in = d->c_in; k.pix_stride = d->pix_stride;
+    k.kh = d->kh; k.kw = d->kw; k.sy = d->sy; k.sx = d->sx; k.h_out = d->h_out; k.w_out = d->w_out;
+    k.c_out = d->c_out; k.pad_mode = d->pad_mode; k.pad = d->pad; k.ld_out = d->ld_out; k.out_coff = d->out_coff;
+    k.ld_res = d->ld_res; k.relu = d->relu; k.splits = d->splits;
+    k.hw_out = d->h_out * d->w_out;
+    k.M = d->n_img * k.hw_out;
+    const int bk = bk_of(d->dtype);
+    k.c_pad = round_up(d->c_in, bk);
+    k.steps_per_tap = k.c_pad / bk;
+    k.nsteps = d->kh * d->kw * k.steps_per_tap;
+    k.steps_per_split = (k.nsteps + d->splits - 1) / d->splits;
+    k.k_total = d->kh * d->kw * k.c_pad;
+    hipStream_t st = (hipStream_t)stream;
+    const bool narrow = d->c_out <= 64;
+    if (d->dtype == CP360_F32) {
+        if (narrow) launch_conv<float, 1, 4>(k, st);
+        else launch_conv<float, 2, 2>(k, st);
+    } else {
+        if (narrow) launch_conv<bf16_raw, 1, 4>(k, st);
+        else launch_conv<bf16_raw, 2, 2>(k, st);
+    }
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const float* bias,
+                                 const void* residual, void* out, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!partial || !out) return CP360_ERR_NULL;
+    const int M = d->n_img * d->h_out * d->w_out;
+    const long long total = (long long)M * (d->c_out / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CP360_F32)
+        hipLaunchKernelGGL((conv_finish_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, partial, d->splits,
+                           bias, (const float*)residual, d->ld_res, (float*)out, d->ld_out, d->out_coff, M, d->c_out,
+                           d->relu);
+    else
+        hipLaunchKernelGGL((conv_finish_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
+                           d->splits, bias, (const bf16_raw*)residual, d->ld_res, (bf16_raw*)out, d->ld_out,
+                           d->out_coff, M, d->c_out, d->relu);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias, const float* c_prev,
+                                float* c_next, void* h_out, int h_dtype, int ld_h, int h_coff, float* h_f32, int M,
+                                int Hc, void* stream) {
+    if (!gates_partial || !bias || !c_prev || !c_next || !h_out) return CP360_ERR_NULL;
+    if (splits < 1 || M <= 0 || Hc <= 0) return CP360_ERR_BAD_SHAPE;
+    if (Hc % 4 != 0 || ld_h % 4 != 0 || h_coff % 4 != 0) return CP360_ERR_ALIGN;
+    const long long total = (long long)M * (Hc / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    if (h_dtype == CP360_F32)
+        hipLaunchKernelGGL((lstm_gates_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial, splits,
+                           bias, c_prev, c_next, (float*)h_out, ld_h, h_coff, h_f32, M, Hc);
+    else if (h_dtype == CP360_BF16)
+        hipLaunchKernelGGL((lstm_gates_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
+                           splits, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

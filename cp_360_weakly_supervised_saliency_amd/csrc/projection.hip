@@ -1,0 +1,187 @@
+// K1 equi -> cube (+ /255, ImageNet normalise, layout, dtype) and K6 cube -> equi
+// (+ channel max).  Both are gathers bounded by HBM bandwidth.
+#include "common.h"
+
+// ------------------------------------------------------------------ K1
+// utils/equi_to_cube.py:112-129 = cv2.remap(img[:, :, c], inX, inY, INTER_LINEAR) per
+// face and channel.  OpenCV's INTER_LINEAR on float maps (imgwarp.cpp: INTER_BITS = 5):
+//   sx = cvRound(x * 32) (round half to even), ix = sx >> 5, fx = (sx & 31) / 32
+//   out = S[iy][ix]*(1-fx)(1-fy) + S[iy][ix+1]*fx(1-fy) + S[iy+1][ix]*(1-fx)fy + S[iy+1][ix+1]*fx*fy
+// with BORDER_CONSTANT 0 for taps outside the image.  One thread per output pixel does
+// the 3 channels (the 12 source bytes / floats of a tap pair are adjacent in HWC), then
+// applies dataset_feat_extractor.py:142 (/255 -> `scale`), utils/utils.py:28-33 (mean /
+// std) and writes NCHW planes (the reference batch, class_activation_model.py:55) or
+// NHWC4 pixels (one 16-byte store) for the fused pipeline.
+template <typename TI> __device__ __forceinline__ float px_load(const TI* p);
+template <> __device__ __forceinline__ float px_load<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float px_load<uint8_t>(const uint8_t* p) { return (float)*p; }
+
+template <typename TI, typename TO, int LAYOUT, bool FIXED>
+__global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ equi, const float2* __restrict__ grid,
+                                                        TO* __restrict__ out, int F, int H, int W, int cd,
+                                                        float m0, float m1, float m2, float s0, float s1, float s2,
+                                                        float scale) {
+    const long long per_frame = 6LL * cd * cd;
+    const long long total = (long long)F * per_frame;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int fr = (int)(idx / per_frame);
+        const int g = (int)(idx - (long long)fr * per_frame);          // face*cd*cd + i*cd + j
+        const float2 xy = grid[g];
+        int ix, iy;
+        float fx, fy;
+        if (FIXED) {
+            const int sx = __float2int_rn(xy.x * 32.f), sy = __float2int_rn(xy.y * 32.f);
+            ix = sx >> 5; iy = sy >> 5;
+            fx = (float)(sx & 31) * (1.f / 32.f);
+            fy = (float)(sy & 31) * (1.f / 32.f);
+        } else {
+            const float flx = floorf(xy.x), fly = floorf(xy.y);
+            ix = (int)flx; iy = (int)fly;
+            fx = xy.x - flx; fy = xy.y - fly;
+        }
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const bool x0ok = ix >= 0 && ix < W, x1ok = ix + 1 >= 0 && ix + 1 < W;
+        const bool y0ok = iy >= 0 && iy < H, y1ok = iy + 1 >= 0 && iy + 1 < H;
+        const TI* base = equi + (size_t)fr * H * W * 3;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float t00 = (x0ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix) * 3 + c) : 0.f;
+            const float t01 = (x1ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix + 1) * 3 + c) : 0.f;
+            const float t10 = (x0ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix) * 3 + c) : 0.f;
+            const float t11 = (x1ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix + 1) * 3 + c) : 0.f;
+            v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+        }
+        v[0] = (v[0] - m0) * s0;
+        v[1] = (v[1] - m1) * s1;
+        v[2] = (v[2] - m2) * s2;
+        if (LAYOUT == 0) {   // [6F, 3, cd, cd]
+            const int face = g / (cd * cd), pix = g - face * cd * cd;
+            const size_t o = ((size_t)(fr * 6 + face) * 3) * cd * cd + pix;
+            if constexpr (sizeof(TO) == 4) {
+                out[o] = v[0]; out[o + (size_t)cd * cd] = v[1]; out[o + 2 * (size_t)cd * cd] = v[2];
+            } else {
+                out[o] = f32_to_bf16(v[0]); out[o + (size_t)cd * cd] = f32_to_bf16(v[1]);
+                out[o + 2 * (size_t)cd * cd] = f32_to_bf16(v[2]);
+            }
+        } else {             // [6F, cd, cd, 4]
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(out + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], 0.f);
+            } else {
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                o.y = (unsigned)f32_to_bf16(v[2]);
+                *reinterpret_cast<uint2*>(out + (size_t)idx * 4) = o;
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO>
+static int launch_e2c(const void* equi, const float* grid, void* out, int F, int H, int W, int cd, const float* mean,
+                      const float* istd, float scale, int layout, int fixed, hipStream_t st) {
+    const long long total = (long long)F * 6 * cd * cd;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define E2C_LAUNCH(L, FX)                                                                                       \
+    hipLaunchKernelGGL((equi2cube_kernel<TI, TO, L, FX>), dim3((unsigned)blocks), dim3(256), 0, st,             \
+                       (const TI*)equi, (const float2*)grid, (TO*)out, F, H, W, cd, mean[0], mean[1], mean[2],  \
+                       istd[0], istd[1], istd[2], scale)
+    if (layout == 0) { if (fixed) E2C_LAUNCH(0, true); else E2C_LAUNCH(0, false); }
+    else             { if (fixed) E2C_LAUNCH(1, true); else E2C_LAUNCH(1, false); }
+#undef E2C_LAUNCH
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_equi2cube(const void* equi, const float* grid, void* out, int F, int H, int W, int cd,
+                               const float* mean3_host, const float* istd3_host, float scale, int in_dtype,
+                               int out_dtype, int out_layout, int cv_fixed_point, void* stream) {
+    if (!equi || !grid || !out || !mean3_host || !istd3_host) return CP360_ERR_NULL;
+    if (F <= 0 || H <= 0 || W <= 0 || cd <= 0 || (out_layout != 0 && out_layout != 1)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == CP360_U8 && out_dtype == CP360_F32)
+        return launch_e2c<uint8_t, float>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
+                                          cv_fixed_point, st);
+    if (in_dtype == CP360_U8 && out_dtype == CP360_BF16)
+        return launch_e2c<uint8_t, bf16_raw>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
+                                             cv_fixed_point, st);
+    if (in_dtype == CP360_F32 && out_dtype == CP360_F32)
+        return launch_e2c<float, float>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
+                                        cv_fixed_point, st);
+    if (in_dtype == CP360_F32 && out_dtype == CP360_BF16)
+        return launch_e2c<float, bf16_raw>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
+                                           cv_fixed_point, st);
+    return CP360_ERR_BAD_DTYPE;
+}
+
+// ------------------------------------------------------------------ K6
+// utils/cube_to_equi.py:37-66 + test_temporal.py:83-84.  One wave per output pixel:
+// the pixel's face and the 4 bilinear taps are wave-uniform, lanes stride over the
+// channels.  NHWC input (layout 1): every tap is one contiguous channel vector ->
+// coalesced; NCHW input (layout 0, the reference's tensor): lanes read with stride w*w.
+// The channel max is a wave shuffle reduction: the 1000 x 2w x 4w full map never has
+// to be written when only the saliency map is wanted.
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void cube2equi_kernel(const float* __restrict__ x,
+                                                        const int8_t* __restrict__ face_map,
+                                                        const float2* __restrict__ coord,
+                                                        float* __restrict__ out_full, float* __restrict__ out_max,
+                                                        int B, int C, int w) {
+    const int npix = 8 * w * w;                       // 2w * 4w
+    const int lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_global >= B * npix) return;
+    const int b = wave_global / npix, pix = wave_global - b * npix;
+    const int f = face_map[pix];
+    const float2 pc = coord[pix];
+    const float flx = floorf(pc.x), fly = floorf(pc.y);
+    const int x0 = (int)flx, y0 = (int)fly;
+    const float fx = pc.x - flx, fy = pc.y - fly;
+    const float wt[4] = {(1.f - fx) * (1.f - fy), fx * (1.f - fy), (1.f - fx) * fy, fx * fy};
+    const int xs[4] = {x0, x0 + 1, x0, x0 + 1}, ys[4] = {y0, y0, y0 + 1, y0 + 1};
+    bool ok[4];
+    size_t off[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok[k] = xs[k] >= 0 && xs[k] < w && ys[k] >= 0 && ys[k] < w;
+        const int yy = ok[k] ? ys[k] : 0, xx = ok[k] ? xs[k] : 0;
+        if (LAYOUT == 1) off[k] = (((size_t)(b * 6 + f) * w + yy) * w + xx) * C;              // + c
+        else             off[k] = ((size_t)(b * 6 + f) * C) * w * w + (size_t)yy * w + xx;    // + c*w*w
+    }
+    const size_t cstride = LAYOUT == 1 ? 1 : (size_t)w * w;
+    float best = -INFINITY;
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = ok[k] ? x[off[k] + (size_t)c * cstride] : 0.f;
+            acc += v * wt[k];
+        }
+        if (out_full) out_full[((size_t)b * C + c) * npix + pix] = acc;
+        best = fmaxf(best, acc);
+    }
+    if (out_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+        if (lane == 0) out_max[(size_t)b * npix + pix] = best;
+    }
+}
+
+extern "C" int cp360_cube2equi(const float* x, const int8_t* face_map, const float* coord, float* out_full,
+                               float* out_max, int B, int C, int w, int layout, void* stream) {
+    if (!x || !face_map || !coord || (!out_full && !out_max)) return CP360_ERR_NULL;
+    if (B <= 0 || C <= 0 || w <= 0 || (layout != 0 && layout != 1)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int waves = B * 8 * w * w;
+    const int blocks = (waves + 3) / 4;
+    if (layout == 1)
+        hipLaunchKernelGGL((cube2equi_kernel<1>), dim3(blocks), dim3(256), 0, st, x, face_map,
+                           (const float2*)coord, out_full, out_max, B, C, w);
+    else
+        hipLaunchKernelGGL((cube2equi_kernel<0>), dim3(blocks), dim3(256), 0, st, x, face_map,
+                           (const float2*)coord, out_full, out_max, B, C, w);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

@@ -1,0 +1,233 @@
+"""ResNet-50 with cube-padded convolutions, module surface of
+/root/reference/model/resnet_cubic.py (``resnet50(pretrained, **kw)``, ``ResNet``,
+``Bottleneck``; state-dict keys = torchvision's), compute in libcp360.so.
+
+The nn.Conv2d / nn.BatchNorm2d children exist only as parameter containers so that
+``state_dict()`` / ``load_state_dict()`` / ``.cuda()`` / ``_modules.get('layer4')
+.register_forward_hook`` behave exactly like the reference's model.  ``forward`` never
+calls them: each block folds its eval-mode BatchNorm into per-channel scale / bias
+(resnet_cubic.py:85-106 with BN eps 1e-5), packs the weights once for the MFMA
+implicit-GEMM kernel (K3) and runs NHWC on the GPU with CubePad(1) fused into the 3x3
+tile loader.  Packed weights are rebuilt when a parameter changes (load_state_dict,
+.cuda()).  Activations between blocks are torch channels_last tensors (logical NCHW,
+physical NHWC) so hooks and callers see the reference's shapes.
+
+Inference only (the north star is the inference path): no autograd through the HIP ops.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .cube_pad import CubePad
+
+__all__ = ['ResNet', 'Bottleneck', 'resnet50']
+
+_DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+
+
+def _fold_bn(bn):
+    """Eval-mode BatchNorm2d as y = x * scale + bias.  One-time parameter preparation
+    on the host in f32; the multiply into the weights happens in the pack kernel."""
+    g, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
+    mu, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
+    scale = g / torch.sqrt(var + bn.eps)
+    return scale, b - mu * scale
+
+
+def _stamp(module, extra=()):
+    ts = list(module.parameters()) + list(module.buffers())
+    return tuple((t.data_ptr(), t._version) for t in ts) + tuple(extra)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, cp=True):
+        super(Bottleneck, self).__init__()
+        if not cp:
+            raise NotImplementedError("only cube padding is supported (the reference's ZeroPad is commented out, "
+                                      "cube_pad.py:219-254)")
+        self.pad = CubePad(1)
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=0, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self.precision = 'fp32'
+        self._plan = None
+        self._plan_stamp = None
+
+    def _plans(self):
+        dt = _DTYPES[self.precision]
+        stamp = _stamp(self, (self.precision,))
+        if self._plan is None or stamp != self._plan_stamp:
+            dev = self.conv1.weight.device
+            s1, b1 = _fold_bn(self.bn1)
+            s2, b2 = _fold_bn(self.bn2)
+            s3, b3 = _fold_bn(self.bn3)
+            plan = {
+                'c1': ops.Conv(self.conv1.weight, s1, b1, 1, 0, True, dt, dev),
+                'c2': ops.Conv(self.conv2.weight, s2, b2, self.stride, 1, True, dt, dev),   # CubePad(1) fused
+                'c3': ops.Conv(self.conv3.weight, s3, b3, 1, 0, True, dt, dev),             # relu after the add
+            }
+            if self.downsample is not None:
+                sd, bd = _fold_bn(self.downsample[1])
+                plan['ds'] = ops.Conv(self.downsample[0].weight, sd, bd, self.stride, 0, False, dt, dev)
+            self._plan, self._plan_stamp = plan, stamp
+        return self._plan
+
+    def forward_nhwc(self, x):
+        p = self._plans()
+        out = p['c1'](x)
+        out = p['c2'](out)
+        res = p['ds'](x) if 'ds' in p else x
+        return p['c3'](out, residual=res)          # conv3 + bn3 + residual + relu in one epilogue
+
+    def forward(self, x):
+        with torch.no_grad():
+            return ops.nchw_view(self.forward_nhwc(ops.as_nhwc(x, _DTYPES[self.precision])))
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000, cp=True, precision='fp32'):
+        self.inplanes = 64
+        super(ResNet, self).__init__()
+        if not cp:
+            raise NotImplementedError("only cube padding is supported")
+        self.cp = cp
+        self.pad3 = CubePad(3)
+        self.pad1 = CubePad(1)
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=0, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=0)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AvgPool2d(7)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        self._stem = None
+        self._stem_stamp = None
+        self._cam = None
+        self._cam_stamp = None
+        self.set_precision(precision)
+        import math
+        for m in self.modules():            # same init as resnet_cubic.py:137-143
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def set_precision(self, precision):
+        if precision not in _DTYPES:
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                m.precision = precision
+        return self
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, cp=self.cp)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, cp=self.cp))
+        return nn.Sequential(*layers)
+
+    # ---- fused-path pieces
+    def _stem_conv(self):
+        dt = _DTYPES[self.precision]
+        stamp = _stamp(self.conv1) + _stamp(self.bn1, (self.precision,))
+        if self._stem is None or stamp != self._stem_stamp:
+            s, b = _fold_bn(self.bn1)
+            self._stem = ops.Conv(self.conv1.weight, s, b, 2, 0, True, dt, self.conv1.weight.device, stem=True)
+            self._stem_stamp = stamp
+        return self._stem
+
+    def cam_conv(self):
+        """CAM as a 1x1 convolution with the shifted classifier weight
+        (class_activation_model.py:46-52: W -= min(W) only when min(W) < 0)."""
+        dt = _DTYPES[self.precision]
+        stamp = _stamp(self.fc, (self.precision,))
+        if self._cam is None or stamp != self._cam_stamp:
+            w = self.fc.weight.detach().float().cpu()
+            mn = w.min()
+            if float(mn) < 0:
+                w = w - mn
+            self._cam = ops.Conv(w.reshape(w.shape[0], w.shape[1], 1, 1), None, None, 1, 0, False, dt,
+                                 self.fc.weight.device)
+            self._cam_stamp = stamp
+        return self._cam
+
+    def stem_nhwc(self, x_nhwc4):
+        """x [6N, H, W, 4] (normalised cube faces, 4th channel 0) -> [6N, H/4, W/4, 64]:
+        CubePad(3) -> conv7x7 s2 + BN + ReLU -> CubePad(1) + maxpool (resnet_cubic.py:165-170)."""
+        xp = ops.cubepad_nhwc(x_nhwc4, 3)
+        x = self._stem_conv()(xp)
+        return ops.cubepad_maxpool3s2(x)
+
+    def features_nhwc(self, x_nhwc4):
+        """Fused path to layer4: [6N, H, W, 4] -> [6N, H/32, W/32, 2048]."""
+        x = self.stem_nhwc(x_nhwc4)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                x = blk.forward_nhwc(x)
+        return x
+
+    def forward(self, x):
+        """x: [6N, 3, H, W] float tensor on the GPU (the reference's batch).  Runs the
+        stem, then layer1..layer4 THROUGH the nn.Module call path so forward hooks fire
+        (CAM hooks 'layer4').  Returns the layer4 features [6N, 2048, H/32, W/32]: the
+        reference goes on to avgpool + fc (resnet_cubic.py:176-178) but its only caller
+        on this path discards that result (class_activation_model.py:64), and fc cannot
+        run at all for cube sizes other than 224."""
+        with torch.no_grad():
+            dt = _DTYPES[self.precision]
+            ops.require_gpu(x)
+            xh = ops.as_nhwc(x.float(), torch.float32)                      # [6N, H, W, 3]
+            x4 = ops.cubepad_nhwc(xh, 0, c_out=4)                           # channel-pad to NHWC4
+            if dt != torch.float32:
+                x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)   # f32 -> bf16 cast
+            y = ops.nchw_view(self.stem_nhwc(x4))
+            y = self.layer1(y)
+            y = self.layer2(y)
+            y = self.layer3(y)
+            y = self.layer4(y)
+            return y
+
+    def load_pretrained_model(self, pretrained_state_dict):
+        """Copy by name, skip size mismatches, KeyError on unknown keys
+        (resnet_cubic.py:183-201)."""
+        own = self.state_dict()
+        for name, param in pretrained_state_dict.items():
+            if name not in own:
+                raise KeyError("unexpected key '{}' in state_dict".format(name))
+            if isinstance(param, nn.Parameter):
+                param = param.data
+            try:
+                own[name].copy_(param)
+            except Exception:
+                print("skip loading key '{}' due to inconsistent size".format(name))
+        self.load_state_dict(own)
+
+
+def resnet50(pretrained=False, **kwargs):
+    """ResNet-50-cubic.  ``pretrained=True`` would download ImageNet weights in the
+    reference (resnet_cubic.py:228-237); there is no network here, so pass a state dict
+    to ``load_pretrained_model`` / ``load_state_dict`` instead."""
+    model = ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)
+    if pretrained:
+        raise RuntimeError("pretrained=True needs a download; load a state_dict instead")
+    return model

@@ -1,0 +1,294 @@
+"""Functional layer over the C ABI (include/cp360.h).  Tensors named *_nhwc are plain
+contiguous torch tensors of shape [N, H, W, C] - the layout the fused pipeline keeps in
+HBM.  torch is used for allocation and stream ownership only; all arithmetic happens in
+libcp360.so.  Every function here fails (RuntimeError / ImportError) without a GPU or
+without the built library - there is no CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, dtype_code, lib, ptr, require_gpu, stream
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # dataset_feat_extractor.py:150-151
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+# ----------------------------------------------------------------------------- CubePad
+def pads_of(lrtd_pad):
+    """model/cube_pad.py:12-20,60-70: an int pads all four sides, else [l, r, t, d]."""
+    if isinstance(lrtd_pad, (int, np.integer)):
+        return (int(lrtd_pad),) * 4
+    p_l, p_r, p_t, p_d = lrtd_pad
+    return int(p_l), int(p_r), int(p_t), int(p_d)
+
+
+def cubepad_table(n, lrtd_pad):
+    """Host int32 [6, Hp, Wp] source-index table of the kernels (no GPU needed)."""
+    pl, pr, pt, pd = pads_of(lrtd_pad)
+    tab = np.empty((6, n + pt + pd, n + pl + pr), dtype=np.int32)
+    check(lib().cp360_cubepad_table_host(n, pl, pr, pt, pd, tab.ctypes.data_as(C.c_void_p)))
+    return tab
+
+
+def cubepad_nchw(x, lrtd_pad):
+    """x [6N, C, n, n] contiguous -> [6N, C, n+pt+pd, n+pl+pr] (cube_pad.py:28-42)."""
+    require_gpu(x)
+    if x.dim() != 4:
+        raise ValueError("CubePad expects a 4-D tensor")
+    if x.shape[2] != x.shape[3]:
+        raise ValueError("CubePad needs square faces (cube_pad.py transposes strips)")
+    pl, pr, pt, pd = pads_of(lrtd_pad)
+    x = x.contiguous()
+    n6, Cc, n, _ = x.shape
+    y = torch.empty((n6, Cc, n + pt + pd, n + pl + pr), dtype=x.dtype, device=x.device)
+    check(lib().cp360_cubepad_nchw(ptr(x), ptr(y), n6, Cc, n, pl, pr, pt, pd, x.element_size(), stream()))
+    return y
+
+
+def cubepad_nhwc(x, lrtd_pad, c_out=None):
+    """x [6N, n, n, C] -> [6N, n+pt+pd, n+pl+pr, c_out or C] (extra channels zero)."""
+    require_gpu(x)
+    pl, pr, pt, pd = pads_of(lrtd_pad)
+    n6, n, n2, Cc = x.shape
+    if n != n2:
+        raise ValueError("CubePad needs square faces")
+    cy = Cc if c_out is None else int(c_out)
+    y = torch.empty((n6, n + pt + pd, n + pl + pr, cy), dtype=x.dtype, device=x.device)
+    check(lib().cp360_cubepad_nhwc(ptr(x), ptr(y), n6, Cc, cy, n, pl, pr, pt, pd, x.element_size(), stream()))
+    return y
+
+
+# ----------------------------------------------------------------------------- layout
+def nchw_to_nhwc(x, out_dtype=None, out=None, coff=0):
+    """[N, C, H, W] contiguous -> [N, H, W, C] (or channels [coff, coff+C) of ``out``)."""
+    require_gpu(x, out)
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    ld = out.shape[3]
+    check(lib().cp360_nchw_to_nhwc(ptr(x), ptr(out), N, Cc, H, W, dtype_code(x.dtype), dtype_code(out.dtype),
+                                   ld, coff, stream()))
+    return out
+
+
+def nhwc_to_nchw(x, out_dtype=None, channels=None, coff=0):
+    """[N, H, W, ld] (channels [coff, coff+channels)) -> [N, channels, H, W]."""
+    require_gpu(x)
+    N, H, W, ld = x.shape
+    Cc = ld if channels is None else channels
+    y = torch.empty((N, Cc, H, W), dtype=out_dtype or x.dtype, device=x.device)
+    check(lib().cp360_nhwc_to_nchw(ptr(x), ptr(y), N, Cc, H, W, dtype_code(x.dtype), dtype_code(y.dtype),
+                                   ld, coff, stream()))
+    return y
+
+
+def as_nhwc(x, dtype=None):
+    """Accept the reference's [N, C, H, W] tensor in either memory format and return
+    an [N, H, W, C] contiguous tensor of ``dtype`` (zero-copy when already so)."""
+    require_gpu(x)
+    v = x.permute(0, 2, 3, 1)
+    if v.is_contiguous() and (dtype is None or dtype == x.dtype):
+        return v
+    if v.is_contiguous():
+        x = x.contiguous()        # rare: physical NHWC but a dtype change is wanted
+    return nchw_to_nhwc(x.contiguous(), out_dtype=dtype or x.dtype)
+
+
+def nchw_view(x_nhwc):
+    """Logical [N, C, H, W] view (torch channels_last strides) of an NHWC tensor."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------- K1 / K6
+def equi2cube(frames, grid, cube_dim, out_dtype=torch.float32, layout='nhwc4', scale=None,
+              mean=IMAGENET_MEAN, std=IMAGENET_STD, cv_fixed_point=True):
+    """frames [F, H, W, 3] u8 / f32 (device), grid [6, cd, cd, 2] f32 (device).
+    Returns [6F, 3, cd, cd] (layout 'nchw') or [6F, cd, cd, 4] (layout 'nhwc4')."""
+    require_gpu(frames, grid)
+    F, H, W, three = frames.shape
+    if three != 3:
+        raise ValueError("frames must be [F, H, W, 3]")
+    frames = frames.contiguous()
+    if scale is None:
+        scale = 1.0 / 255.0 if frames.dtype == torch.uint8 else 1.0
+    shape = (6 * F, 3, cube_dim, cube_dim) if layout == 'nchw' else (6 * F, cube_dim, cube_dim, 4)
+    out = torch.empty(shape, dtype=out_dtype, device=frames.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(np.float32(1.0) / np.float32(v)) for v in std])
+    check(lib().cp360_equi2cube(ptr(frames), ptr(grid), ptr(out), F, H, W, cube_dim, m, s, float(scale),
+                                dtype_code(frames.dtype), dtype_code(out_dtype), 0 if layout == 'nchw' else 1,
+                                1 if cv_fixed_point else 0, stream()))
+    return out
+
+
+def cube2equi(x, face_map, coord, layout='nchw', want_full=True, want_max=False):
+    """x f32 [6B, C, w, w] ('nchw') or [6B, w, w, C] ('nhwc'); face_map int8 [2w,4w];
+    coord f32 [2w,4w,2] pixel-space sampling positions.  Returns (full, max)."""
+    require_gpu(x, face_map, coord)
+    x = x.contiguous()
+    if layout == 'nchw':
+        n6, Cc, w, _ = x.shape
+    else:
+        n6, w, _, Cc = x.shape
+    if n6 % 6:
+        raise ValueError("batch must be a multiple of 6 faces")
+    B = n6 // 6
+    full = torch.empty((B, Cc, 2 * w, 4 * w), dtype=torch.float32, device=x.device) if want_full else None
+    mx = torch.empty((B, 2 * w, 4 * w), dtype=torch.float32, device=x.device) if want_max else None
+    check(lib().cp360_cube2equi(ptr(x), ptr(face_map), ptr(coord), ptr(full), ptr(mx), B, Cc, w,
+                                0 if layout == 'nchw' else 1, stream()))
+    return full, mx
+
+
+# ----------------------------------------------------------------------------- convolution
+def _choose_splits(M, c_out, nsteps, narrow):
+    """Split-K factor.  The chip runs 256 CUs x 2 resident workgroups (LDS-bound), so a
+    launch is balanced when its workgroup count is a multiple of 512 (or much larger).
+    Small-M GEMMs (ConvLSTM: M = 294*B, K = 18000..36000) get there by splitting K;
+    each extra split costs one more f32 slab of [M, c_out] written and re-read."""
+    bn, bm = (64, 256) if narrow else (128, 128)
+    wgs = math.ceil(c_out / bn) * math.ceil(M / bm)
+    if wgs >= 2048 or nsteps < 16:
+        return 1
+    best, best_cost = 1, None
+    for s in range(1, 33):
+        if s > 1 and nsteps // s < 8:
+            break
+        tot = wgs * s
+        cost = math.ceil(tot / 512) * 512 / tot * (1.0 + 0.02 * (s - 1))
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s, cost
+    return best
+
+
+class Conv:
+    """One convolution of the path with its packed weights resident on the device.
+
+    weight: f32 [c_out, c_in, kh, kw] (torch, any device); ``scale`` / ``bias``: per
+    output channel f32 (BatchNorm folding happens in the pack kernel: w * scale[n]).
+    pad > 0 means "preceded by CubePad(pad)" (fused into the tile loader).
+    """
+
+    def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, relu=False, dtype=torch.float32,
+                 device='cuda', stem=False):
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.stride = int(stride)
+        self.pad = int(pad)
+        self.relu = bool(relu)
+        self.stem = bool(stem)
+        w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.c_out, self.c_in_w, self.kh_w, self.kw_w = w.shape
+        if stem:
+            assert (self.c_in_w, self.kh_w, self.kw_w) == (3, 7, 7)
+            self.c_in, self.kh, self.kw, self.pix_stride = 32, 7, 1, 4
+        else:
+            self.c_in, self.kh, self.kw, self.pix_stride = self.c_in_w, self.kh_w, self.kw_w, self.c_in_w
+        self.bias = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        sc = None if scale is None else scale.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        d = self._desc(6, max(self.kh, 8), max(self.kw, 8) if not stem else 16, 1)
+        nbytes = lib().cp360_conv_packed_bytes(C.byref(d))
+        if nbytes == 0:
+            raise ValueError("unsupported convolution geometry for libcp360")
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(lib().cp360_conv_pack_weights(C.byref(d), ptr(w), ptr(sc), ptr(self.packed), 1 if stem else 0, stream()))
+        self._partial = None
+
+    def out_hw(self, h_in, w_in):
+        p2 = 2 * self.pad
+        return (h_in + p2 - self.kh) // self.stride + 1, \
+               ((w_in + p2 - self.kw_w) // self.stride + 1 if self.stem else (w_in + p2 - self.kw) // self.stride + 1)
+
+    def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None):
+        d = ConvDesc()
+        d.dtype = dtype_code(self.dtype)
+        d.n_img, d.h_in, d.w_in = n_img, h_in, w_in
+        d.c_in, d.pix_stride = self.c_in, self.pix_stride
+        d.kh, d.kw, d.sy, d.sx = self.kh, self.kw, self.stride, self.stride
+        d.h_out, d.w_out = self.out_hw(h_in, w_in)
+        d.c_out = self.c_out
+        d.pad_mode, d.pad = (1 if self.pad > 0 else 0), self.pad
+        d.ld_out = self.c_out if ld_out is None else ld_out
+        d.out_coff, d.ld_res = out_coff, ld_res
+        d.relu = int(self.relu if relu is None else relu)
+        d.splits = splits
+        return d
+
+    def nsteps(self):
+        bk = 32 if self.dtype == torch.float32 else 64
+        return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
+
+    def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None):
+        """x [n_img, h, w, c] NHWC (for the stem: the materialised CubePad(3) output
+        [n_img, h+6, w+6, 4]).  Returns [n_img, h_out, w_out, c_out] in self.dtype, or
+        with raw_f32=True the (partial [splits, M, c_out] f32, splits) pair whose
+        reduction / bias / activation the caller finishes (cp360_lstm_gates, CAM)."""
+        require_gpu(x, residual, out)
+        n_img, h_in, w_in, cx = x.shape
+        if x.dtype != self.dtype:
+            raise ValueError("activation dtype %s != conv dtype %s" % (x.dtype, self.dtype))
+        if not self.stem and cx != self.c_in:
+            raise ValueError("input has %d channels, conv expects %d" % (cx, self.c_in))
+        if self.stem and cx != 4:
+            raise ValueError("stem expects an NHWC4 input")
+        h_out, w_out = self.out_hw(h_in, w_in)
+        M = n_img * h_out * w_out
+        if splits is None:
+            splits = _choose_splits(M, self.c_out, self.nsteps(), self.c_out <= 64)
+        ld_out = self.c_out if out is None else out.shape[3]
+        ld_res = 0 if residual is None else residual.shape[3]
+        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res)
+        L = lib()
+        if raw_f32 or splits > 1:
+            need = splits * M * self.c_out
+            if partial_buf is not None:          # caller-owned destination for the raw sums
+                if partial_buf.numel() < need or partial_buf.dtype != torch.float32:
+                    raise ValueError("partial_buf too small")
+                check(L.cp360_conv_forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
+                                           ptr(partial_buf), stream()))
+                return partial_buf, splits
+            if self._partial is None or self._partial.numel() < need:
+                self._partial = torch.empty(need, dtype=torch.float32, device=x.device)
+            check(L.cp360_conv_forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
+                                       ptr(self._partial), stream()))
+            if raw_f32:
+                return self._partial, splits
+            if out is None:
+                out = torch.empty((n_img, h_out, w_out, self.c_out), dtype=self.dtype, device=x.device)
+            check(L.cp360_conv_finish(C.byref(d), ptr(self._partial), ptr(self.bias), ptr(residual), ptr(out),
+                                      stream()))
+            return out
+        if out is None:
+            out = torch.empty((n_img, h_out, w_out, self.c_out), dtype=self.dtype, device=x.device)
+        check(L.cp360_conv_forward(C.byref(d), ptr(x), ptr(self.packed), ptr(self.bias), ptr(residual), ptr(out),
+                                   None, stream()))
+        return out
+
+
+def cubepad_maxpool3s2(x):
+    """CubePad(1) + MaxPool2d(3, 2, 0) on NHWC (resnet_cubic.py:169-170)."""
+    require_gpu(x)
+    n6, n, _, Cc = x.shape
+    ho = (n + 2 - 3) // 2 + 1
+    y = torch.empty((n6, ho, ho, Cc), dtype=x.dtype, device=x.device)
+    check(lib().cp360_cubepad_maxpool3s2(ptr(x), ptr(y), n6, n, Cc, dtype_code(x.dtype), stream()))
+    return y
+
+
+def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, Hc):
+    check(lib().cp360_lstm_gates(ptr(partial), splits, ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out),
+                                 dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc, stream()))
+
+
+def window_minmax(x, B, per_clip, minmax, scratch):
+    check(lib().cp360_window_minmax(ptr(x), ptr(minmax), ptr(scratch), B, per_clip, stream()))
+
+
+def window_normalize(x, minmax, y, y_coff, y2, B, T, t, P, Cc):
+    check(lib().cp360_window_normalize(ptr(x), ptr(minmax), ptr(y), dtype_code(y.dtype), y.shape[-1], y_coff,
+                                       ptr(y2), B, T, t, P, Cc, stream()))

@@ -1,0 +1,82 @@
+"""End-to-end engine: equirectangular frames in HBM -> saliency maps in HBM.
+
+    frames u8 [B, T, H, W, 3]
+      K1 equi -> cube (+/255, ImageNet normalise)        dataset_feat_extractor.py:138-157
+      K2 CubePad(3) -> K3 ResNet-50-cubic -> layer4      model/resnet_cubic.py:163-175
+      K4 CAM (shifted fc weight as 1x1 conv)             class_activation_model.py:46-83
+      K7 window min/max + normalise                      test_temporal.py:66-73
+      K5 T x ConvLSTM step                               model/clstm.py:42-82
+      K6 cube -> equi + channel max                      test_temporal.py:82-85
+    saliency f32 [B, 2w, 4w]
+
+It is the fused counterpart of the reference's two drivers chained through .npy files
+(inference.sh): nothing leaves the device between the stages.  Each clip is one
+window (non-overlapping clips; the reference's stride-1 sliding window repeats the
+ConvLSTM work seq_len times and is available through ``ClipRunner`` directly).
+"""
+import torch
+
+from . import ops
+from .model.resnet_cubic import resnet50
+from .model.clstm import ConvLSTMCell
+from .static_model.class_activation_model import cam_device
+from .temporal_model.test_temporal import ClipRunner
+from .utils.cube_to_equi import Cube2Equi
+from .utils.equi_to_cube import Equi2Cube
+
+
+class SaliencyEngine:
+    def __init__(self, resnet_state, clstm_state, equi_hw=(1024, 2048), cube_dim=224, clips=1, frames=16,
+                 precision='fp32', device='cuda', align_corners=False, cv_fixed_point=True,
+                 input_size=1000, hidden_size=1000, frame_chunk=None):
+        self.device = torch.device(device)
+        self.precision = precision
+        self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
+        self.B, self.T = int(clips), int(frames)
+        self.H, self.W = equi_hw
+        self.cube_dim = int(cube_dim)
+        self.w = self.cube_dim // 32
+        # frames per static-stage launch group (bounds activation memory; None = all)
+        self.frame_chunk = frame_chunk or self.B * self.T
+
+        self.resnet = resnet50(precision=precision)
+        missing, unexpected = self.resnet.load_state_dict(_to_tensors(resnet_state), strict=False)
+        bad = [k for k in missing if not k.endswith('num_batches_tracked')]
+        if bad or unexpected:
+            raise KeyError("resnet state dict mismatch: missing %s unexpected %s" % (bad, unexpected))
+        self.resnet.to(self.device).eval()
+        self.cell = ConvLSTMCell(input_size, hidden_size, precision=precision)
+        self.cell.load_state_dict(_to_tensors(clstm_state))           # strict, as test_temporal.py:149
+        self.cell.to(self.device).eval()
+        self.e2c = Equi2Cube(self.cube_dim, (self.H, self.W), device=self.device, cv_fixed_point=cv_fixed_point)
+        self.c2e = Cube2Equi(self.w, align_corners=align_corners, device=self.device)
+        self.runner = ClipRunner(self.cell, self.c2e, self.B, self.T, self.w)
+        self.cam = torch.empty((self.B, self.T, 6 * self.w * self.w, input_size), dtype=torch.float32,
+                               device=self.device)
+
+    def static_stage(self, frames):
+        """frames u8/f32 [F, H, W, 3] on the device -> CAM f32 [F, 6*w*w, 1000] written
+        into self.cam (frame-major, NHWC)."""
+        F = frames.shape[0]
+        cam_flat = self.cam.view(self.B * self.T, 6 * self.w * self.w, -1)
+        for lo in range(0, F, self.frame_chunk):
+            hi = min(F, lo + self.frame_chunk)
+            x4 = self.e2c.to_cube_batch(frames[lo:hi], out_dtype=self.dtype, layout='nhwc4')
+            cam_device(x4, self.resnet, out=cam_flat[lo:hi])      # CAM conv writes the clip buffer directly
+        return self.cam
+
+    def temporal_stage(self, cam=None):
+        return self.runner.run(self.cam if cam is None else cam)
+
+    def __call__(self, frames):
+        """frames [B, T, H, W, 3] (u8 or f32, device) -> saliency f32 [B, 2w, 4w]."""
+        with torch.no_grad():
+            B, T = frames.shape[:2]
+            if (B, T) != (self.B, self.T):
+                raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
+            self.static_stage(frames.reshape(B * T, self.H, self.W, 3))
+            return self.temporal_stage()
+
+
+def _to_tensors(sd):
+    return {k: (v if torch.is_tensor(v) else torch.from_numpy(v)) for k, v in sd.items()}

@@ -1,0 +1,200 @@
+/* libcp360 - C ABI of the MI355X (gfx950) 360-saliency hot path.
+ *
+ * The reference (hsientzucheng/CP-360-Weakly-Supervised-Saliency) has no FFI layer:
+ * its "operator API" is the Python call surface of model/cube_pad.py,
+ * model/resnet_cubic.py, model/clstm.py, utils/equi_to_cube.py,
+ * utils/cube_to_equi.py and static_model/class_activation_model.py.  The Python
+ * shims in cp_360_weakly_supervised_saliency_amd/ keep those names and bind the
+ * entry points below through ctypes.  Each entry point cites
+ * the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every buffer is caller-allocated DEVICE memory
+ *    unless the parameter name ends in _host;
+ *  - every function is asynchronous on the hipStream_t passed as `void* stream`
+ *    (0 = the null stream) and never allocates, frees or synchronises;
+ *  - return value: 0 = ok, negative = cp360_status; no exceptions, no exit()
+ *    (the reference print+exit()s on batch % 6 != 0, cube_pad.py:33-35);
+ *  - face order along the batch dimension is [back, down, front, left, right, top]
+ *    (cube_pad.py:49), batches are frame-major / face-minor ([6N, ...]);
+ *  - "NCHW" is the reference's tensor layout; "NHWC" (channels innermost) is the
+ *    layout the fused pipeline keeps in HBM between kernels.
+ */
+#ifndef CP360_H
+#define CP360_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    CP360_OK = 0,
+    CP360_ERR_BAD_SHAPE = -1,      /* negative / zero / inconsistent sizes        */
+    CP360_ERR_BATCH_NOT_6N = -2,   /* cube_pad.py:33-35                           */
+    CP360_ERR_NOT_SQUARE = -3,     /* CubePad transposes strips: faces must be n x n */
+    CP360_ERR_BAD_DTYPE = -4,
+    CP360_ERR_NULL = -5,
+    CP360_ERR_ALIGN = -6,          /* channel counts / strides not 16-byte friendly */
+    CP360_ERR_HIP = -7,            /* a HIP runtime call failed                   */
+    CP360_ERR_UNSUPPORTED = -8
+} cp360_status;
+
+typedef enum {
+    CP360_F32 = 0,
+    CP360_BF16 = 1,
+    CP360_U8 = 3
+} cp360_dtype;
+
+const char* cp360_strerror(int status);
+/* library / ABI version: major*10000 + minor*100 + patch */
+int cp360_version(void);
+
+/* ------------------------------------------------------------------ K2: CubePad
+ * Replaces CubePad.forward / CubePadding.forward, model/cube_pad.py:28-42,95-216
+ * (33 torch.cat + 8 index_select per call).  Pure permutation-with-replication of
+ * input elements -> results are bit-exact for every dtype.
+ */
+
+/* Host helper: the (face, i, j) -> flat source index table the kernels implement
+ * (f'*n*n + i'*n + j'), int32 [6, n+pt+pd, n+pl+pr] written to host memory.  Same
+ * inline function as the device code; used by tests and by callers that want to
+ * gather on their own. */
+int cp360_cubepad_table_host(int n, int pl, int pr, int pt, int pd, int32_t* table_host);
+
+/* x [n6, C, n, n] -> y [n6, C, n+pt+pd, n+pl+pr], elem_size in {1, 2, 4, 8} bytes. */
+int cp360_cubepad_nchw(const void* x, void* y, int n6, int C, int n,
+                       int pl, int pr, int pt, int pd, int elem_size, void* stream);
+
+/* x [n6, n, n, C] -> y [n6, n+pt+pd, n+pl+pr, Cy] with Cy >= C (extra channels are
+ * written as zero); C*elem_size and Cy*elem_size must be multiples of 4 bytes. */
+int cp360_cubepad_nhwc(const void* x, void* y, int n6, int C, int Cy, int n,
+                       int pl, int pr, int pt, int pd, int elem_size, void* stream);
+
+/* ------------------------------------------------------------------ layout glue */
+/* [N, C, H, W] <-> [N, H, W, C]; dtype CP360_F32 or CP360_BF16 on either side (the
+ * fused pipeline's bf16 mode converts here).  The NHWC side may be a channel slice of
+ * a wider pixel: ld = elements per NHWC pixel (0 = C, dense), coff = first channel -
+ * this is how clstm.py:55's torch.cat((input_, prev_hidden), 1) is laid out. */
+int cp360_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W,
+                       int in_dtype, int out_dtype, int ld_y, int y_coff, void* stream);
+int cp360_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, int W,
+                       int in_dtype, int out_dtype, int ld_x, int x_coff, void* stream);
+
+/* ------------------------------------------------------------------ K1: equi -> cube
+ * Replaces Equi2Cube.to_cube (utils/equi_to_cube.py:112-129, 18 cv2.remap calls per
+ * frame) fused with the x/255 of dataset_feat_extractor.py:142, im_norm
+ * (utils/utils.py:28-33), the float32 cast and the HWC->CHW permute of
+ * class_activation_model.py:55.
+ *   equi   [F, H, W, 3]   u8 or f32 (HWC, as decoded frames arrive)
+ *   grid   [6, cd, cd, 2] f32 (x, y) - the float32 maps to_cube hands to cv2.remap
+ *   out    F frames x 6 faces:
+ *            out_layout 0: [6F, 3, cd, cd]           (NCHW, the reference's batch)
+ *            out_layout 1: [6F, cd, cd, 4]           (NHWC, 4th channel = 0)
+ *   value  = (bilinear(equi * scale) - mean[c]) * istd[c]
+ *   cv_fixed_point != 0: OpenCV INTER_LINEAR coordinate quantisation (1/32 px,
+ *   round-half-even), taps outside the image contribute 0 (BORDER_CONSTANT).
+ */
+int cp360_equi2cube(const void* equi, const float* grid, void* out,
+                    int F, int H, int W, int cd,
+                    const float* mean3_host, const float* istd3_host, float scale,
+                    int in_dtype, int out_dtype, int out_layout, int cv_fixed_point,
+                    void* stream);
+
+/* ------------------------------------------------------------------ K6: cube -> equi
+ * Replaces Cube2Equi.to_equi_nn (utils/cube_to_equi.py:37-66: six full-size
+ * grid_samples + masked scatter) and, when out_max != NULL, the channel max of
+ * temporal_model/test_temporal.py:83-84.
+ *   x        [6B, C, w, w] (layout 0, NCHW) or [6B, w, w, C] (layout 1, NHWC), f32
+ *   face_map [2w, 4w] int8, coord [2w, 4w, 2] f32 = pixel-space sampling position
+ *            (x, y) already un-normalised on the host (align_corners folded in)
+ *   out_full [B, C, 2w, 4w] f32 or NULL;  out_max [B, 2w, 4w] f32 or NULL
+ */
+int cp360_cube2equi(const float* x, const int8_t* face_map, const float* coord,
+                    float* out_full, float* out_max, int B, int C, int w,
+                    int layout, void* stream);
+
+/* ------------------------------------------------------------------ K3/K4/K5: convolution
+ * Implicit-GEMM convolution on MFMA.  Replaces nn.Conv2d(+BatchNorm2d eval)(+ReLU)
+ * (+residual add) of model/resnet_cubic.py:85-106,163-175, the per-face CAM GEMM of
+ * static_model/class_activation_model.py:70-83 (as a 1x1 convolution) and the three
+ * 3x3 convolutions of model/clstm.py:56-64.  Zero padding never occurs on this path
+ * (every reference conv has padding=0); the CubePad(p) that precedes a 3x3 / 7x7 conv
+ * is fused into the tile loader (pad_mode 1) instead of being materialised.
+ */
+typedef struct {
+    int dtype;        /* CP360_F32 (mfma_f32_16x16x4_f32, exact f32) or CP360_BF16
+                         (mfma_f32_16x16x32_bf16, f32 accumulate) - activations,
+                         packed weights and outputs all have this type            */
+    int n_img;        /* images (6 * frames)                                      */
+    int h_in, w_in;   /* spatial size of the (unpadded) input tensor              */
+    int c_in;         /* K elements taken per tap (normally = channels)           */
+    int pix_stride;   /* elements between neighbouring input pixels (>= c_in for a
+                         normal conv; 4 for the stem's 8-pixel x 4-channel trick) */
+    int kh, kw;       /* taps                                                     */
+    int sy, sx;       /* stride in input pixels                                   */
+    int h_out, w_out;
+    int c_out;
+    int pad_mode;     /* 0: no padding; 1: fused CubePad(pad) - needs h_in == w_in */
+    int pad;
+    int ld_out;       /* elements between output pixels (>= c_out)                */
+    int out_coff;     /* first output channel inside an ld_out-wide pixel         */
+    int ld_res;       /* residual pixel stride (0 when residual == NULL)          */
+    int relu;
+    int splits;       /* split-K factor (>= 1); > 1 needs `partial`               */
+} cp360_conv_desc;
+
+/* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */
+size_t cp360_conv_packed_bytes(const cp360_conv_desc* d);
+/* Bytes of split-K workspace (0 when splits == 1). */
+size_t cp360_conv_partial_bytes(const cp360_conv_desc* d);
+/* Pack OIHW f32 weights [c_out, c_in_w, kh_w, kw_w] times scale[c_out] (BatchNorm
+ * folding; NULL = 1) into the kernel's [c_out_pad][tap][c_pad] layout and dtype.
+ * stem_mode != 0 packs a [c_out, 3, 7, 7] filter for the kh=7, kw=1, c_in=32 form
+ * (k index = kx*4 + c). */
+int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const float* scale,
+                            void* packed, int stem_mode, void* stream);
+/* out = act(conv(in) + bias (+ residual)).  bias f32 [c_out] or NULL.
+ * d->splits > 1, or out == NULL: the raw f32 sums go to `partial`
+ * ([splits, M, c_out], M = n_img*h_out*w_out; bias / residual / relu NOT applied)
+ * and cp360_conv_finish or cp360_lstm_gates must follow. */
+int cp360_conv_forward(const cp360_conv_desc* d, const void* in, const void* packed_w,
+                       const float* bias, const void* residual, void* out,
+                       float* partial, void* stream);
+/* out = act(sum_s partial[s] + bias (+ residual)) in d->dtype at the desc's ld_out/out_coff. */
+int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const float* bias,
+                      const void* residual, void* out, void* stream);
+
+/* ------------------------------------------------------------------ K3b: max-pool
+ * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),
+ * NHWC, pad fused: x [n6, n, n, C] -> y [n6, (n-1)/2+... , .., C] with
+ * h_out = (n + 2 - 3)/2 + 1. */
+int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ K5: ConvLSTM gates
+ * model/clstm.py:68-80.  gates_partial: f32 [splits, M, 4*Hc] pre-activation sums
+ * (split-K slabs of the Gates convolution, channel order in|remember|out|cell),
+ * bias f32 [4*Hc]; c_prev/c_next f32 [M, Hc]; h_out (dtype h_dtype) is written at
+ * h_out[m*ld_h + h_coff + j]; h_f32 (optional) receives an f32 copy [M, Hc]. */
+int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias,
+                     const float* c_prev, float* c_next, void* h_out, int h_dtype,
+                     int ld_h, int h_coff, float* h_f32, int M, int Hc, void* stream);
+
+/* ------------------------------------------------------------------ K7: window normalise
+ * temporal_model/test_temporal.py:66-67,70-73,77: per clip min / max over the whole
+ * window, then (x - mn) / (mx - mn).
+ *   x [B, T, P, C] f32 (P = 6*w*w pixels, NHWC) ; minmax [B, 2] f32 (out) */
+int cp360_window_minmax(const float* x, float* minmax, float* scratch /* [B*256*2] */,
+                        int B, size_t per_clip, void* stream);
+/* y[b, p, y_coff + c] = (x[b, t, p, c] - mn_b) / (mx_b - mn_b); y has pixel stride ld_y
+ * and dtype y_dtype; optional second destination y2 (f32, [B, P, C]) for the cell. */
+int cp360_window_normalize(const float* x, const float* minmax, void* y, int y_dtype,
+                           int ld_y, int y_coff, float* y2, int B, int T, int t,
+                           int P, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CP360_H */

@@ -1,0 +1,82 @@
+"""CPU tests of the C-ABI library: it loads, exports every symbol the header declares,
+its host-side CubePad index function is bit-identical to the oracle (the same inline
+function drives every device kernel), and argument errors come back as status codes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import o_cubepad
+from cp_360_weakly_supervised_saliency_amd import _lib, ops
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(REPO, 'include', 'cp360.h')).read()
+    declared = set(re.findall(r'\b(cp360_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libcp360.so does not export %s" % name
+    assert declared == set(_lib.SYMBOLS)
+    assert L.cp360_version() >= 100
+    assert L.cp360_strerror(-2).decode().startswith('CubePad size mismatch')
+
+
+@pytest.mark.parametrize('n', [1, 2, 4, 5, 7])
+def test_cubepad_table_matches_oracle_all_pad_combinations(n):
+    for pl in range(0, min(n, 3) + 1):
+        for pr in range(0, min(n, 3) + 1):
+            for pt in range(0, min(n, 3) + 1):
+                for pd in range(0, min(n, 3) + 1):
+                    got = ops.cubepad_table(n, [pl, pr, pt, pd])
+                    want = o_cubepad.cubepad_table(n, pl, pr, pt, pd)
+                    assert np.array_equal(got, want), (n, pl, pr, pt, pd)
+
+
+@pytest.mark.parametrize('n,p', [(224, 3), (112, 1), (56, 1), (28, 1), (14, 1), (7, 1), (16, 1), (9, 2)])
+def test_cubepad_table_network_sizes(n, p):
+    assert np.array_equal(ops.cubepad_table(n, p), o_cubepad.cubepad_table(n, p, p, p, p))
+
+
+def test_status_codes_without_gpu():
+    L = _lib.lib()
+    dummy = C.c_void_p(16)
+    assert L.cp360_cubepad_nchw(dummy, dummy, 5, 1, 4, 1, 1, 1, 1, 4, None) == -2      # batch % 6
+    assert L.cp360_cubepad_nchw(None, dummy, 6, 1, 4, 1, 1, 1, 1, 4, None) == -5       # null
+    assert L.cp360_cubepad_nchw(dummy, dummy, 6, 1, 4, 1, 1, 1, 1, 3, None) == -4      # elem size
+    assert L.cp360_cubepad_nchw(dummy, dummy, 6, 1, 4, -1, 1, 1, 1, 4, None) == -1
+    d = _lib.ConvDesc()
+    assert L.cp360_conv_packed_bytes(C.byref(d)) == 0
+    with pytest.raises(ValueError):
+        _lib.check(-2)
+    with pytest.raises(_lib.Cp360Error):
+        _lib.check(-7)
+
+
+def test_conv_packed_size_and_desc_checks():
+    import torch
+    L = _lib.lib()
+    d = _lib.ConvDesc()
+    for k, v in dict(dtype=0, n_img=6, h_in=7, w_in=7, c_in=2000, pix_stride=2000, kh=3, kw=3, sy=1, sx=1,
+                     h_out=7, w_out=7, c_out=4000, pad_mode=1, pad=1, ld_out=4000, out_coff=0, ld_res=0,
+                     relu=1, splits=1).items():
+        setattr(d, k, v)
+    # f32: K per tap padded to 32 -> 2016; rows padded to 128 -> 4096
+    assert L.cp360_conv_packed_bytes(C.byref(d)) == 4096 * 9 * 2016 * 4
+    d.dtype = 1   # bf16: K per tap padded to 64 -> 2048
+    assert L.cp360_conv_packed_bytes(C.byref(d)) == 4096 * 9 * 2048 * 2
+    d.n_img = 5
+    assert L.cp360_conv_packed_bytes(C.byref(d)) == 0          # fused CubePad needs 6N images
+    d.n_img, d.splits = 6, 4
+    assert L.cp360_conv_partial_bytes(C.byref(d)) == 4 * 294 * 4000 * 4
+    assert torch is not None
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    with pytest.raises(RuntimeError):
+        ops.cubepad_nchw(torch.zeros(6, 1, 4, 4), 1)

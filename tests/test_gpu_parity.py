@@ -1,0 +1,438 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, reached through
+the Python shims -> ctypes -> the C ABI of libcp360.so, against the CPU oracle and the
+reference-generated golden fixtures.
+
+Tolerances: index / copy work (CubePad, face_map) bit-exact; fp32 paths 1e-5 relative
+per op and 1e-3 absolute on saliency maps / window-normalised CAM (north star); bf16
+paths are checked against their own looser bounds (AUC/CC gate: tests/test_metrics.py).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from oracle import o_cubepad, o_e2c, o_c2e, o_resnet, o_clstm
+from cp_360_weakly_supervised_saliency_amd import ops
+from cp_360_weakly_supervised_saliency_amd.model.cube_pad import CubePad
+from cp_360_weakly_supervised_saliency_amd.model.resnet_cubic import resnet50
+from cp_360_weakly_supervised_saliency_amd.model.clstm import ConvLSTMCell
+from cp_360_weakly_supervised_saliency_amd.static_model.class_activation_model import CAM
+from cp_360_weakly_supervised_saliency_amd.temporal_model.test_temporal import ClipRunner
+from cp_360_weakly_supervised_saliency_amd.utils.equi_to_cube import Equi2Cube
+from cp_360_weakly_supervised_saliency_amd.utils.cube_to_equi import Cube2Equi
+from cp_360_weakly_supervised_saliency_amd.utils import hashrng, synth
+from cp_360_weakly_supervised_saliency_amd.pipeline import SaliencyEngine
+from tests.golden import make_golden as mg
+from tests import parity_helpers as ph
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def rel_err(got, want):
+    return float(np.max(np.abs(got - want)) / max(float(np.max(np.abs(want))), 1e-30))
+
+
+# ------------------------------------------------------------------ K2 CubePad
+def test_cubepad_golden_small_bit_exact(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'cubepad_small.npz'))
+    for k in range(len(mg.CUBEPAD_SMALL)):
+        x, y, pad = z['x%d' % k], z['y%d' % k], [int(v) for v in z['pad%d' % k]]
+        got = CubePad(pad)(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert got.shape == y.shape and np.array_equal(got, y), (k, pad)
+
+
+def test_cubepad_golden_hashed_bit_exact(golden_dir):
+    want = json.load(open(os.path.join(golden_dir, 'cubepad_sha256.json')))
+    for k, (n, p, C) in enumerate(mg.CUBEPAD_HASHED):
+        x = mg.cubepad_input(n, C, 1, 2000 + k)
+        got = CubePad(p)(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert sha(got) == want['%d_%d_%d' % (n, p, C)], (n, p, C)
+
+
+@pytest.mark.parametrize('dtype', [torch.uint8, torch.bfloat16, torch.float32, torch.float64])
+def test_cubepad_every_element_size(dtype):
+    x = hashrng.integers(77, (12, 5, 9, 9), 0, 200).astype(np.float64)
+    xt = torch.from_numpy(x).to(dtype)
+    bits = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[xt.element_size()]
+    want = o_cubepad.cubepad(xt.view(bits).numpy(), [2, 1, 3, 0])          # compare raw bit patterns
+    got = CubePad([2, 1, 3, 0])(xt.to(DEV)).cpu()
+    assert got.dtype == dtype and np.array_equal(got.view(bits).numpy(), want)
+
+
+def test_cubepad_nhwc_and_channel_padding():
+    x = hashrng.integers(78, (6, 7, 14, 14), 0, 1 << 20).astype(np.float32)       # NCHW
+    want = o_cubepad.cubepad(x, 1)
+    xt = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).to(DEV)   # NHWC, C = 7 (odd word count)
+    got = ops.cubepad_nhwc(xt, 1).cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.array_equal(got, want)
+    got8 = ops.cubepad_nhwc(xt, 1, c_out=8).cpu().numpy()
+    assert np.array_equal(got8[..., :7].transpose(0, 3, 1, 2), want) and not got8[..., 7].any()
+    # channels_last tensors take the NHWC kernel through the module too
+    cl = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert np.array_equal(CubePad(1)(cl).cpu().numpy(), want)
+
+
+def test_cubepad_errors():
+    with pytest.raises(ValueError):
+        CubePad(1)(torch.zeros(5, 2, 4, 4, device=DEV))
+    with pytest.raises(ValueError):
+        CubePad(1)(torch.zeros(6, 2, 4, 5, device=DEV))
+    y = CubePad(0)(torch.ones(6, 1, 3, 3, device=DEV))
+    assert y.shape == (6, 1, 3, 3) and bool((y == 1).all())
+
+
+def test_layout_round_trip_and_slices():
+    x = hashrng.normal(79, (4, 37, 5, 9))
+    xt = torch.from_numpy(x).to(DEV)
+    nhwc = ops.nchw_to_nhwc(xt)
+    assert np.array_equal(nhwc.cpu().numpy(), x.transpose(0, 2, 3, 1))
+    assert np.array_equal(ops.nhwc_to_nchw(nhwc).cpu().numpy(), x)
+    wide = torch.zeros((4, 5, 9, 80), device=DEV)
+    ops.nchw_to_nhwc(xt, out=wide, coff=40)
+    w = wide.cpu().numpy()
+    assert np.array_equal(w[..., 40:77], x.transpose(0, 2, 3, 1)) and not w[..., :40].any() and not w[..., 77:].any()
+    assert np.array_equal(ops.nhwc_to_nchw(wide, channels=37, coff=40).cpu().numpy(), x)
+    bf = ops.nchw_to_nhwc(xt, out_dtype=torch.bfloat16)
+    assert torch.equal(bf.cpu(), torch.from_numpy(x.transpose(0, 2, 3, 1).copy()).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------ K1 equi -> cube
+@pytest.mark.parametrize('H,W,cd', [(64, 128, 16), (256, 512, 64), (960, 1920, 224)])
+def test_equi2cube_matches_oracle(H, W, cd):
+    frame = synth.frame_u8(5, H, W)
+    e = Equi2Cube(cd, (H, W))
+    want = ph.oracle_cubes(frame, cd)                                   # [6,3,cd,cd] f32, fixed point
+    ft = torch.from_numpy(frame[None]).to(DEV)
+    got = e.to_cube_batch(ft, layout='nchw').cpu().numpy()
+    assert np.max(np.abs(got - want)) <= 2e-5
+    got4 = e.to_cube_batch(ft, layout='nhwc4').cpu().numpy()
+    assert np.max(np.abs(got4[..., :3].transpose(0, 3, 1, 2) - want)) <= 2e-5 and not got4[..., 3].any()
+    # float input, reference-style to_cube (no normalisation), dict of 6 HWC faces
+    img = frame.astype(np.float64) / 255.0
+    faces = e.to_cube(img)
+    ref = o_e2c.to_cube(img, cd)
+    for f in range(6):
+        assert faces[f].shape == (cd, cd, 3) and np.max(np.abs(faces[f] - ref[f])) <= 2e-6
+    # plain-float bilinear switch
+    e2 = Equi2Cube(cd, (H, W), cv_fixed_point=False)
+    got_f = e2.to_cube_batch(ft, layout='nchw').cpu().numpy()
+    want_f = ph.oracle_cubes(frame, cd, fixed_point=False)
+    assert np.max(np.abs(got_f - want_f)) <= 2e-4      # fp32 fractional weights vs float64
+    bf = e.to_cube_batch(ft, out_dtype=torch.bfloat16, layout='nhwc4').float().cpu().numpy()
+    assert np.max(np.abs(bf[..., :3].transpose(0, 3, 1, 2) - want)) <= 2e-2
+
+
+# ------------------------------------------------------------------ K6 cube -> equi
+@pytest.mark.parametrize('w', [4, 7, 8, 16])
+def test_cube2equi_golden(golden_dir, w):
+    z = np.load(os.path.join(golden_dir, 'c2e.npz'))
+    c = Cube2Equi(w)
+    x = torch.from_numpy(z['nn_in_%d' % w]).to(DEV)
+    got = c.to_equi_nn(x).cpu().numpy()
+    assert got.shape == (1, 5, 2 * w, 4 * w)
+    assert np.max(np.abs(got - z['nn_out_%d' % w])) <= 2e-6
+    sal = c.saliency(x).cpu().numpy()[0]
+    assert np.max(np.abs(sal - z['nn_out_%d' % w][0].max(axis=0))) <= 2e-6
+
+
+def test_cube2equi_nhwc_batched_max_and_align_corners():
+    w, C, B = 7, 1000, 3
+    x = hashrng.normal(81, (6 * B, C, w, w))
+    for ac in (False, True):
+        c = Cube2Equi(w, align_corners=ac)
+        xt = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).to(DEV)
+        sal = c.saliency(xt, layout='nhwc').cpu().numpy()
+        for b in range(B):
+            want = o_c2e.saliency_from_hidden(x[6 * b:6 * b + 6], align_corners=ac)
+            assert np.max(np.abs(sal[b] - want)) <= 5e-6, (ac, b)
+
+
+# ------------------------------------------------------------------ K3 convolution
+def _conv_ref(x_nchw, w, scale, bias, stride, pad, relu, res=None):
+    xt = torch.from_numpy(x_nchw)
+    if pad:
+        xt = o_resnet.cubepad_t(xt, pad)
+    wt = torch.from_numpy(w)
+    if scale is not None:
+        wt = wt * torch.from_numpy(scale)[:, None, None, None]
+    y = Fn.conv2d(xt, wt, None if bias is None else torch.from_numpy(bias), stride=stride)
+    if res is not None:
+        y = y + torch.from_numpy(res)
+    return (Fn.relu(y) if relu else y).numpy()
+
+
+CONV_CASES = [
+    # n_img, cin, cout, n, k, stride, pad, relu, res, splits
+    (6, 64, 64, 12, 1, 1, 0, True, False, None),       # narrow tile (c_out <= 64)
+    (6, 64, 256, 12, 1, 1, 0, True, True, None),       # residual epilogue
+    (12, 128, 128, 10, 3, 2, 1, True, False, None),    # CubePad fused, stride on the 3x3
+    (6, 256, 512, 8, 1, 2, 0, False, False, None),     # strided 1x1 (downsample)
+    (6, 40, 72, 7, 3, 1, 1, True, False, 3),           # K tail (40 % 32), split-K + finish
+    (6, 2000, 136, 7, 3, 1, 1, True, False, 4),        # ConvLSTM-like K (2000 per tap)
+    (18, 32, 1000, 7, 1, 1, 0, False, False, None),    # CAM-like c_out = 1000 (N tail)
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_conv_matches_torch_cpu(case, prec):
+    n_img, cin, cout, n, k, stride, pad, relu, use_res, splits = case
+    dt = torch.float32 if prec == 'fp32' else torch.bfloat16
+    seed = 9000 + cin + cout
+    x = hashrng.normal(seed, (n_img, cin, n, n))
+    w = hashrng.normal(seed + 1, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
+    scale = hashrng.uniform(seed + 2, (cout,), 0.5, 1.5)
+    bias = hashrng.normal(seed + 3, (cout,), 0, 0.1)
+    ho = (n + 2 * pad - k) // stride + 1
+    res = hashrng.normal(seed + 4, (n_img, cout, ho, ho)) if use_res else None
+    if prec == 'bf16':     # the oracle sees the same rounded operands; accumulation stays f32
+        rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+        x_ref, res_ref = rb(x), (None if res is None else rb(res))
+        w_ref = (torch.from_numpy(w) * torch.from_numpy(scale)[:, None, None, None]).to(torch.bfloat16).float().numpy()
+        want = _conv_ref(x_ref, w_ref, None, bias, stride, pad, relu, res_ref)
+    else:
+        want = _conv_ref(x, w, scale, bias, stride, pad, relu, res)
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), stride, pad, relu, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    rt = None if res is None else ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
+    got = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits), out_dtype=torch.float32).cpu().numpy()
+    assert got.shape == want.shape
+    tol = 2e-5 if prec == 'fp32' else 1.2e-2     # bf16: one output rounding (2^-8 relative)
+    assert rel_err(got, want) <= tol, rel_err(got, want)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_stem_conv_and_maxpool(prec):
+    dt = torch.float32 if prec == 'fp32' else torch.bfloat16
+    x = hashrng.normal(9100, (6, 3, 32, 32))
+    w = hashrng.normal(9101, (64, 3, 7, 7), 0, (2.0 / (49 * 64)) ** 0.5)
+    scale = hashrng.uniform(9102, (64,), 0.5, 1.5)
+    bias = hashrng.normal(9103, (64,), 0, 0.1)
+    if prec == 'bf16':
+        rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+        w_ref = (torch.from_numpy(w) * torch.from_numpy(scale)[:, None, None, None]).to(torch.bfloat16).float().numpy()
+        stem_ref = _conv_ref(rb(x), w_ref, None, bias, 2, 3, True)
+    else:
+        stem_ref = _conv_ref(x, w, scale, bias, 2, 3, True)
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 2, 0, True, dt, DEV, stem=True)
+    x3 = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV))                   # [6,32,32,3] f32
+    x4 = ops.cubepad_nhwc(x3, 0, c_out=4)
+    if prec == 'bf16':
+        x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)
+    xp = ops.cubepad_nhwc(x4, 3)
+    y = conv(xp)
+    got = ops.nhwc_to_nchw(y, out_dtype=torch.float32).cpu().numpy()
+    assert got.shape == stem_ref.shape == (6, 64, 16, 16)
+    assert rel_err(got, stem_ref) <= (2e-5 if prec == 'fp32' else 1.2e-2)
+    pooled = ops.nhwc_to_nchw(ops.cubepad_maxpool3s2(y), out_dtype=torch.float32).cpu().numpy()
+    want_pool = Fn.max_pool2d(o_resnet.cubepad_t(torch.from_numpy(got), 1), 3, 2, 0).numpy()
+    assert np.array_equal(pooled, want_pool)     # max of identical values: exact
+
+
+# ------------------------------------------------------------------ ResNet-50-cubic + CAM
+def _load_resnet(prec='fp32'):
+    sd = synth.resnet50_state(seed=1)
+    m = resnet50(precision=prec)
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith('num_batches_tracked') for k in missing)
+    return m.to(DEV).eval(), sd
+
+
+def test_resnet_state_dict_keys_match_reference_names():
+    m = resnet50()
+    keys = set(m.state_dict().keys())
+    for k in synth.resnet50_state(seed=1):
+        assert k in keys
+    assert len(keys) == 320      # 320 entries incl. num_batches_tracked
+
+
+def test_resnet_layer4_small_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'resnet_cam.npz'))
+    m, _ = _load_resnet()
+    cubes = mg.synth_cubes(4000 + 64, 64)
+    x = torch.from_numpy(np.ascontiguousarray(cubes.transpose(0, 3, 1, 2))).to(DEV)
+    seen = []
+    h = m._modules.get('layer4').register_forward_hook(lambda mod, i, o: seen.append(o))
+    y = m(x)
+    h.remove()
+    assert len(seen) == 1 and seen[0].shape == (6, 2048, 2, 2)
+    got = seen[0].cpu().numpy()
+    assert rel_err(got, z['layer4_s']) <= 3e-4
+    assert np.array_equal(y.cpu().numpy(), got)
+
+
+def test_cam_full_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'resnet_cam.npz'))
+    m, sd = _load_resnet()
+    cubes = mg.synth_cubes(4000 + 224, 224)
+    score, feat, wsm = CAM(cubes, None, m, 'layer4', 'fc.weight', use_gpu=True)
+    assert score.shape == (6, 1000, 7, 7) and feat.shape == (6, 2048, 7, 7) and wsm.shape == (1000, 2048)
+    assert np.array_equal(wsm[::97, ::53], z['wsm_pick'])
+    assert rel_err(feat[:, ::8], z['layer4_f']) <= 3e-4
+    assert rel_err(score, z['cam_f']) <= 3e-4
+    # north-star gate: window-normalised CAM within 1e-3 absolute
+    mn, mx = z['cam_f'].min(), z['cam_f'].max()
+    assert np.max(np.abs((score - mn) / (mx - mn) - (z['cam_f'] - mn) / (mx - mn))) <= 1e-3
+    # the model's fc.weight is NOT mutated (the reference's CPU path does, survey a7)
+    assert np.array_equal(m.fc.weight.detach().cpu().numpy(), sd['fc.weight'])
+
+
+def test_cam_bf16_close_to_fp32_oracle(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'resnet_cam.npz'))
+    m, _ = _load_resnet('bf16')
+    score, _, _ = CAM(mg.synth_cubes(4000 + 224, 224), None, m, 'layer4', 'fc.weight')
+    mn, mx = z['cam_f'].min(), z['cam_f'].max()
+    err = np.abs((score - mn) / (mx - mn) - (z['cam_f'] - mn) / (mx - mn))
+    assert np.max(err) <= 5e-2 and np.mean(err) <= 5e-3, (np.max(err), np.mean(err))
+
+
+# ------------------------------------------------------------------ ConvLSTM
+def test_clstm_small_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'clstm.npz'))
+    sd = synth.clstm_state(seed=7, input_size=8, hidden_size=8)
+    cell = ConvLSTMCell(8, 8)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    cell = cell.to(DEV).eval()
+    x = torch.from_numpy(hashrng.uniform(5000, (12, 8, 4, 4))).to(DEV)
+    h = torch.from_numpy(hashrng.uniform(5001, (12, 8, 4, 4))).to(DEV)
+    c = torch.from_numpy(hashrng.uniform(5002, (12, 8, 4, 4))).to(DEV)
+    h1, c1 = cell(x, [h, c])
+    h2, c2 = cell(x, [h1, c1])
+    for got, key in ((h1, 'small_h1'), (c1, 'small_c1'), (h2, 'small_h2'), (c2, 'small_c2')):
+        assert np.max(np.abs(got.cpu().numpy() - z[key])) <= 2e-6, key
+    h0, c0 = cell(x)       # prev_state=None -> zeros (clstm.py:47-52)
+    zero = torch.zeros(12, 8, 4, 4)
+    hw, cw = o_clstm.clstm_step(x.cpu(), zero, zero, {k: torch.from_numpy(v) for k, v in sd.items()})
+    assert np.max(np.abs(h0.cpu().numpy() - hw.numpy())) <= 2e-6 and np.max(np.abs(c0.cpu().numpy() - cw.numpy())) <= 2e-6
+
+
+@pytest.fixture(scope='module')
+def full_cell_state():
+    return synth.clstm_state(seed=2)
+
+
+def _full_cell(sd, prec):
+    cell = ConvLSTMCell(1000, 1000, precision=prec)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert sorted(cell.state_dict().keys()) == sorted(sd.keys())       # strict names (test_temporal.py:149)
+    return cell.to(DEV).eval()
+
+
+@pytest.mark.parametrize('T', [5, 16])
+def test_clstm_full_window_golden(golden_dir, full_cell_state, T):
+    z = np.load(os.path.join(golden_dir, 'clstm.npz'))
+    cell = _full_cell(full_cell_state, 'fp32')
+    frames = synth.cam_clip(6000 + T, T)                                # [T,6,1000,7,7]
+    cam = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 1, 3, 4, 2)).reshape(1, T, 294, 1000)).to(DEV)
+    runner = ClipRunner(cell, Cube2Equi(7), 1, T)
+    sal, hid = runner.run(cam, return_hidden=True)
+    hid_nchw = ops.nhwc_to_nchw(hid).cpu().numpy()
+    assert np.max(np.abs(hid_nchw.reshape(-1)[z['pick']] - z['full_hidden_pick_T%d' % T])) <= 1e-3
+    assert np.max(np.abs(sal.cpu().numpy()[0] - z['full_map_T%d' % T])) <= 1e-3     # north-star gate
+
+
+def test_clstm_batched_clips_equal_single(full_cell_state):
+    """B clips in one GEMM (M = 294*B, other split-K factor) == each clip alone."""
+    cell = _full_cell(full_cell_state, 'fp32')
+    T, B = 3, 4
+    cams = [synth.cam_clip(6100 + b, T) for b in range(B)]
+    pack = lambda f: np.ascontiguousarray(f.transpose(0, 1, 3, 4, 2)).reshape(T, 294, 1000)
+    c2e = Cube2Equi(7)
+    batched = ClipRunner(cell, c2e, B, T).run(torch.from_numpy(np.stack([pack(f) for f in cams])).to(DEV)).cpu().numpy()
+    single = ClipRunner(cell, c2e, 1, T)
+    for b in range(B):
+        one = single.run(torch.from_numpy(pack(cams[b])[None]).to(DEV)).cpu().numpy()[0]
+        assert np.max(np.abs(batched[b] - one)) <= 2e-5
+    want = o_clstm.window_saliency(cams[1], {k: torch.from_numpy(v) for k, v in full_cell_state.items()})
+    assert np.max(np.abs(batched[1] - want)) <= 1e-3
+
+
+def test_clstm_bf16_window(golden_dir, full_cell_state):
+    z = np.load(os.path.join(golden_dir, 'clstm.npz'))
+    cell = _full_cell(full_cell_state, 'bf16')
+    frames = synth.cam_clip(6000 + 5, 5)
+    cam = torch.from_numpy(np.ascontiguousarray(frames.transpose(0, 1, 3, 4, 2)).reshape(1, 5, 294, 1000)).to(DEV)
+    sal = ClipRunner(cell, Cube2Equi(7), 1, 5).run(cam).cpu().numpy()[0]
+    err = np.abs(sal - z['full_map_T5'])
+    assert np.max(err) <= 2e-2, np.max(err)       # bf16 moves the map by ~1e-3
+
+
+def test_window_minmax_and_normalize():
+    B, T, P, C = 3, 4, 294, 1000
+    x = hashrng.normal(83, (B, T, P, C), 5.0, 100.0)
+    xt = torch.from_numpy(x).to(DEV)
+    mm = torch.empty((B, 2), device=DEV)
+    scratch = torch.empty((B * 512,), device=DEV)
+    ops.window_minmax(xt, B, T * P * C, mm, scratch)
+    got = mm.cpu().numpy()
+    assert np.array_equal(got[:, 0], x.reshape(B, -1).min(1)) and np.array_equal(got[:, 1], x.reshape(B, -1).max(1))
+    y = torch.zeros((B, P, 2 * C), device=DEV)
+    y2 = torch.empty((B, P, C), device=DEV)
+    ops.window_normalize(xt, mm, y, C, y2, B, T, 2, P, C)
+    for b in range(B):
+        mn, mx = x[b].min(), x[b].max()
+        want = (x[b, 2] - mn) / (mx - mn)
+        assert np.array_equal(y[b, :, C:].cpu().numpy(), want) and np.array_equal(y2[b].cpu().numpy(), want)
+    assert not y[:, :, :C].any()
+
+
+# ------------------------------------------------------------------ end to end
+@pytest.fixture(scope='module')
+def e2e_small():
+    H, W, cd, T, B = 256, 512, 64, 3, 2
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=3)
+    clips = np.stack([synth.clip_u8(20 + b, T, H, W) for b in range(B)])
+    refs = [ph.oracle_pipeline(clips[b], rs, cs, cd, return_all=True) for b in range(B)]
+    return dict(H=H, W=W, cd=cd, T=T, B=B, rs=rs, cs=cs, clips=clips, refs=refs)
+
+
+def test_pipeline_fp32_end_to_end(e2e_small):
+    s = e2e_small
+    eng = SaliencyEngine(s['rs'], s['cs'], (s['H'], s['W']), s['cd'], clips=s['B'], frames=s['T'], precision='fp32')
+    sal = eng(torch.from_numpy(s['clips']).to(DEV)).cpu().numpy()
+    cam = eng.cam.cpu().numpy()                       # [B,T,24,1000] NHWC
+    for b in range(s['B']):
+        ref_sal, ref_cams, _ = s['refs'][b]
+        want_cam = ref_cams.transpose(0, 1, 3, 4, 2).reshape(s['T'], -1, 1000)
+        mn, mx = want_cam.min(), want_cam.max()
+        assert np.max(np.abs((cam[b] - mn) / (mx - mn) - (want_cam - mn) / (mx - mn))) <= 1e-3
+        assert sal[b].shape == (4, 8)
+        assert np.max(np.abs(sal[b] - ref_sal)) <= 1e-3
+    # a second call on the same engine (buffers reused) is deterministic
+    sal2 = eng(torch.from_numpy(s['clips']).to(DEV)).cpu().numpy()
+    assert np.array_equal(sal, sal2)
+
+
+def test_pipeline_bf16_end_to_end(e2e_small):
+    s = e2e_small
+    eng = SaliencyEngine(s['rs'], s['cs'], (s['H'], s['W']), s['cd'], clips=s['B'], frames=s['T'], precision='bf16')
+    sal = eng(torch.from_numpy(s['clips']).to(DEV)).cpu().numpy()
+    for b in range(s['B']):
+        err = np.abs(sal[b] - s['refs'][b][0])
+        assert np.max(err) <= 5e-2, np.max(err)
+
+
+def test_pipeline_full_size_one_frame_fp32():
+    """Config C1/C2 shape: one 960x1920 frame -> 6x224^2 -> CAM, against the oracle."""
+    H, W, cd = 960, 1920, 224
+    rs = synth.resnet50_state(seed=1)
+    frame = synth.frame_u8(31, H, W)
+    want = ph.oracle_cam_frames(frame[None], rs, cd)[0]                  # [6,1000,7,7]
+    m, _ = _load_resnet()
+    e = Equi2Cube(cd, (H, W))
+    x4 = e.to_cube_batch(torch.from_numpy(frame[None]).to(DEV))
+    from cp_360_weakly_supervised_saliency_amd.static_model.class_activation_model import cam_device
+    score, _ = cam_device(x4, m)
+    got = ops.nhwc_to_nchw(score).cpu().numpy()
+    mn, mx = want.min(), want.max()
+    assert np.max(np.abs((got - mn) / (mx - mn) - (want - mn) / (mx - mn))) <= 1e-3
