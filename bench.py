@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on N MI355X GPUs of one node (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs C3/C4 per-GPU shard): each rank owns `--clips` clips of
+`--frames` synthetic 1024x2048 u8 equirectangular frames, resident in HBM before the
+timed region.  One step = the whole path over that batch: equi->cube (K1), CubePad +
+ResNet-50-cubic (K2/K3), CAM (K4), window normalise (K7), T ConvLSTM steps (K5),
+cube->equi + channel max (K6), and for N > 1 one RCCL all-gather of the saliency maps.
+Metric: frames/s = N * clips * frames * K / max-over-ranks wall time.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (the ConvLSTM implicit-GEMM convolution, timed live with HIP events) and
+`cpu_baseline` (the oracle on the host cores, bounded sample, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from cp_360_weakly_supervised_saliency_amd import dist as cpdist          # noqa: E402
+from cp_360_weakly_supervised_saliency_amd import ops                      # noqa: E402
+from cp_360_weakly_supervised_saliency_amd.pipeline import SaliencyEngine  # noqa: E402
+from cp_360_weakly_supervised_saliency_amd.utils import synth              # noqa: E402
+
+PEAK = {'bf16': 2500.0, 'fp32': 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+class LaunchTimer:
+    """HIP-event timer around tagged kernel launches on torch's current stream (the
+    stream libcp360 launches on).  Events are resolved after the timed region."""
+
+    def __init__(self):
+        self.active = False
+        self.records = []          # (tag, flops, start_event, end_event)
+
+    def wrap(self, tag, flops, fn):
+        if not self.active or not tag.startswith('clstm.'):
+            return fn()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn()
+        b.record()
+        self.records.append((tag, flops, a, b))
+        return rc
+
+    def summary(self):
+        by = {}
+        for tag, flops, a, b in self.records:
+            ms = a.elapsed_time(b)
+            d = by.setdefault(tag, {'n': 0, 'ms': 0.0, 'flops': flops})
+            d['n'] += 1
+            d['ms'] += ms
+        return by
+
+
+def cpu_baseline(H, W, cd, precision_note):
+    """The oracle (numpy / torch-CPU restatement of the reference, oracle/) on the host
+    cores for a bounded sample: ONE clip of 2 frames at the benchmark resolution through
+    the whole path (static stage x2, ConvLSTM x2, cube->equi)."""
+    from tests.parity_helpers import oracle_pipeline
+    torch.set_num_threads(os.cpu_count() or 1)
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=2)
+    clip = synth.clip_u8(3, 2, H, W)
+    t0 = time.time()
+    oracle_pipeline(clip, rs, cs, cd)
+    dt = time.time() - t0
+    return {'value': round(2.0 / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 clip x 2 frames %dx%d -> 6x%d^2, oracle fp32 (torch-CPU conv, numpy remap), %.1f s'
+                      % (H, W, cd, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--precision', default=os.environ.get('CP360_PRECISION', 'bf16'), choices=['fp32', 'bf16'])
+    ap.add_argument('--clips', type=int, default=4, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=16, help='frames per clip')
+    ap.add_argument('--equi', default='1024x2048')
+    ap.add_argument('--cube', type=int, default=224)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--frame-chunk', type=int, default=0, help='frames per static-stage group (0 = all)')
+    args = ap.parse_args()
+
+    rank, world, local = cpdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    H, W = (int(v) for v in args.equi.split('x'))
+    B, T = args.clips, args.frames
+
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=2)
+    eng = SaliencyEngine(rs, cs, (H, W), args.cube, clips=B, frames=T, precision=args.precision, device=dev,
+                         frame_chunk=args.frame_chunk or None)
+    del rs, cs
+    # this rank's clips (global clip id = rank*B + b), resident in HBM before timing
+    frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + rank * B + b, T, H, W)) for b in range(B)]).to(dev)
+    n_clips = world * B
+
+    timer = LaunchTimer()
+    ops.LAUNCH_TIMER = timer
+
+    def step():
+        sal = eng(frames)
+        return cpdist.gather_maps(sal, n_clips, rank, world)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    cpdist.barrier()
+    torch.cuda.synchronize()
+    timer.active = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    cpdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.active = False
+    elapsed = cpdist.max_over_ranks(elapsed, dev)
+    assert out.shape[0] == n_clips and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        frames_total = world * B * T * args.steps
+        ksum = timer.summary()
+        # dominant kernel: the K = 36000 ConvLSTM convolutions (Conv2 / Gates have the same shape)
+        dom = [ksum[k] for k in ('clstm.Conv2', 'clstm.Gates') if k in ksum]
+        roof = None
+        if dom:
+            n = sum(d['n'] for d in dom)
+            ms = sum(d['ms'] for d in dom) / n
+            flops = dom[0]['flops']
+            ach = flops / (ms * 1e-3) / 1e12
+            traffic = None
+            tp = os.path.join(REPO, 'profiles', 'traffic_%s.json' % args.precision)
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get('conv_igemm_clstm_bytes_per_launch')
+            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (ConvLSTM Conv2/Gates, M=%d N=4000 K=36000)'
+                    % (6 * B * eng.w * eng.w), 'achieved': round(ach, 2), 'peak': PEAK[args.precision],
+                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.precision], 4), 'traffic': traffic,
+                    'avg_launch_ms': round(ms, 4), 'launches_timed': n, 'flops_per_launch': flops}
+        line = {
+            'metric': 'frames/sec end-to-end 1024x2048 equi->saliency',
+            'value': round(frames_total / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C3/C4 per-GPU shard: %d clips x %d frames %dx%d u8 equi -> 6x%d^2 cube -> '
+                                   'CubePad ResNet-50 -> CAM -> ConvLSTM x%d -> cube_to_equi saliency %dx%d'
+                                   % (B, T, H, W, args.cube, T, 2 * eng.w, 4 * eng.w),
+                       'clips_per_gpu': B, 'frames_per_clip': T, 'equi': [H, W], 'cube_dim': args.cube,
+                       'parallelism': 'clips sharded over %d GPU(s), 1 all-gather of maps' % world},
+            'roofline': roof,
+            'cpu_baseline': None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(H, W, args.cube, args.precision)
+        print(json.dumps(line))
+    cpdist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,70 @@
+"""Data-parallel sharding of clips over the GPUs of one node (one process per GPU).
+
+Clips share no state (the ConvLSTM recurrence is confined to a clip), so the path
+shards by clip with no data-path collective; the only exchange is one all-gather of the
+per-clip saliency maps ([clips_per_rank, 2w, 4w] f32 - a few KB per rank, latency-bound
+over xGMI).  ``torch.distributed`` backend "nccl" is RCCL on ROCm; the same code runs
+under "gloo" on CPU for the tests.  The reference has no distributed code at all
+(SURVEY.md section 2): this layer is new, its contract is "gathered result == the
+single-process result, clip for clip".
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torchrun).
+    Returns (rank, world_size, local_rank).  Single-process when WORLD_SIZE is unset."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_clips(n_clips, rank, world):
+    """Clip ids owned by ``rank``: contiguous blocks, sizes differ by at most one
+    (ragged totals are allowed; the gather pads to the largest block)."""
+    base, extra = divmod(n_clips, world)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+def gather_maps(local_maps, n_clips, rank, world):
+    """local_maps: [len(shard_clips(...)), h, w] f32 on this rank's device.
+    Returns [n_clips, h, w] on every rank, ordered by clip id (one all_gather)."""
+    if world == 1:
+        return local_maps
+    base, extra = divmod(n_clips, world)
+    cap = base + (1 if extra else 0)
+    h, w = local_maps.shape[1:]
+    send = torch.zeros((cap, h, w), dtype=local_maps.dtype, device=local_maps.device)
+    send[: local_maps.shape[0]] = local_maps
+    recv = torch.empty((world, cap, h, w), dtype=local_maps.dtype, device=local_maps.device)
+    dist.all_gather_into_tensor(recv, send) if hasattr(dist, 'all_gather_into_tensor') and \
+        dist.get_backend() != 'gloo' else dist.all_gather(list(recv.unbind(0)), send)
+    parts = [recv[r, : base + (1 if r < extra else 0)] for r in range(world)]
+    return torch.cat(parts, dim=0)
+
+
+def max_over_ranks(value, device):
+    """Scalar max across ranks (bench timing contract)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

@@ -69,6 +69,8 @@ class ConvLSTMCell(nn.Module):
                 'g': ops.Conv(self.Gates.weight, None, None, 1, 1, False, dt, dev),   # bias added in the gate kernel
                 'gbias': self.Gates.bias.detach().to(device=dev, dtype=torch.float32).contiguous(),
             }
+            for k, name in (('c1', 'clstm.Conv1'), ('c2', 'clstm.Conv2'), ('g', 'clstm.Gates')):
+                self._plan[k].tag = name
             self._plan_stamp = stamp
         return self._plan
 

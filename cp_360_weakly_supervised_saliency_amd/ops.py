@@ -166,6 +166,12 @@ def _choose_splits(M, c_out, nsteps, narrow):
     return best
 
 
+# Optional launch timer (bench.py installs one): an object with
+# ``wrap(tag, flops, fn)`` that brackets the conv_forward launch with HIP events on the
+# current stream.  None = no instrumentation (default).
+LAUNCH_TIMER = None
+
+
 class Conv:
     """One convolution of the path with its packed weights resident on the device.
 
@@ -182,6 +188,7 @@ class Conv:
         self.pad = int(pad)
         self.relu = bool(relu)
         self.stem = bool(stem)
+        self.tag = 'conv'
         w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
         self.c_out, self.c_in_w, self.kh_w, self.kw_w = w.shape
         if stem:
@@ -244,17 +251,23 @@ class Conv:
         ld_res = 0 if residual is None else residual.shape[3]
         d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res)
         L = lib()
+        def forward(*a):
+            if LAUNCH_TIMER is None:
+                return L.cp360_conv_forward(*a)
+            flops = 2.0 * M * self.c_out * self.c_in_w * self.kh_w * self.kw_w
+            return LAUNCH_TIMER.wrap(self.tag, flops, lambda: L.cp360_conv_forward(*a))
+
         if raw_f32 or splits > 1:
             need = splits * M * self.c_out
             if partial_buf is not None:          # caller-owned destination for the raw sums
                 if partial_buf.numel() < need or partial_buf.dtype != torch.float32:
                     raise ValueError("partial_buf too small")
-                check(L.cp360_conv_forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
+                check(forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
                                            ptr(partial_buf), stream()))
                 return partial_buf, splits
             if self._partial is None or self._partial.numel() < need:
                 self._partial = torch.empty(need, dtype=torch.float32, device=x.device)
-            check(L.cp360_conv_forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
+            check(forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
                                        ptr(self._partial), stream()))
             if raw_f32:
                 return self._partial, splits
@@ -265,7 +278,7 @@ class Conv:
             return out
         if out is None:
             out = torch.empty((n_img, h_out, w_out, self.c_out), dtype=self.dtype, device=x.device)
-        check(L.cp360_conv_forward(C.byref(d), ptr(x), ptr(self.packed), ptr(self.bias), ptr(residual), ptr(out),
+        check(forward(C.byref(d), ptr(x), ptr(self.packed), ptr(self.bias), ptr(residual), ptr(out),
                                    None, stream()))
         return out
 

@@ -1,0 +1,74 @@
+"""world_size-2 gloo test (CPU) of the clip sharding + all-gather layer: the gathered
+maps equal the single-process result clip for clip, including ragged clip counts."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_saliency(clip_id):
+    """Deterministic stand-in for a clip's [14, 28] saliency map (the HIP pipeline
+    cannot run on CPU and the oracle is too slow to run per rank here; the layer under
+    test is sharding + gather order, which is independent of the map values)."""
+    r = np.random.RandomState(1234 + clip_id)
+    return r.rand(14, 28).astype(np.float32)
+
+
+def _worker(rank, world, port, n_clips, q):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from cp_360_weakly_supervised_saliency_amd import dist as d
+    r, w, _ = d.init_from_env(backend='gloo')
+    mine = d.shard_clips(n_clips, r, w)
+    local = torch.from_numpy(np.stack([_fake_saliency(c) for c in mine])) if mine else torch.zeros((0, 14, 28))
+    d.barrier()
+    allmaps = d.gather_maps(local, n_clips, r, w)
+    t = d.max_over_ranks(1.0 + r, 'cpu')
+    q.put((rank, mine, allmaps.numpy(), t))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_clips', [4, 5, 1])
+def test_two_rank_gather_equals_single_process(n_clips):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([_fake_saliency(c) for c in range(n_clips)])
+    owned = []
+    for rank, mine, allmaps, t in res:
+        assert allmaps.shape == want.shape and np.array_equal(allmaps, want)
+        assert t == 2.0
+        owned += mine
+    assert sorted(owned) == list(range(n_clips))
+
+
+def test_shard_is_balanced_partition():
+    from cp_360_weakly_supervised_saliency_amd.dist import shard_clips
+    for n in (0, 1, 7, 32, 33):
+        for world in (1, 2, 4, 8):
+            parts = [shard_clips(n, r, world) for r in range(world)]
+            assert sum(parts, []) == list(range(n))
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1
