@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Time the oracle's two CPU hot spots at several torch thread counts (picks the
+thread count the cpu_baseline leg of bench.py should use on this host)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import o_resnet, o_clstm
+from cp_360_weakly_supervised_saliency_amd.utils import synth, hashrng
+rs = {k: torch.from_numpy(v) for k, v in synth.resnet50_state(1).items()}
+cs = {k: torch.from_numpy(v) for k, v in synth.clstm_state(2).items()}
+x = torch.from_numpy(hashrng.normal(1, (6, 3, 224, 224)))
+f = torch.from_numpy(hashrng.uniform(2, (6, 1000, 7, 7)))
+for nt in (8, 16, 32, 64, 128, 256):
+    if nt > (os.cpu_count() or 1):
+        break
+    torch.set_num_threads(nt)
+    o_resnet.resnet50_layer4(x, rs)
+    t0 = time.time(); o_resnet.resnet50_layer4(x, rs); t1 = time.time()
+    o_clstm.clstm_step(f, f, f, cs); t2 = time.time()
+    print('threads %3d: resnet %.3f s  clstm step %.3f s' % (nt, t1 - t0, t2 - t1), flush=True)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs of tools/collect_profile.sh into the committed summary
+under profiles/: per-kernel time table (kernel-trace --stats) and per-launch HBM traffic
+of the dominant kernel from the PMC passes.
+
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE counts exactly half of a wide coalesced streaming read, so
+traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes.
+
+    python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/r01_<tag>
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(d, pat):
+    hits = glob.glob(os.path.join(d, '**', pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    out = {}
+    lines = []
+    st = find(os.path.join(src, 'trace'), '*kernel_stats.csv')
+    if st:
+        rows = list(csv.DictReader(open(st)))
+        lines.append('| kernel | calls | total ms | avg us | % |')
+        lines.append('|---|---|---|---|---|')
+        for r in rows[:14]:
+            lines.append('| `%s` | %s | %.3f | %.2f | %s |' % (r['Name'][:70], r['Calls'],
+                         float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, r['Percentage']))
+        out['kernel_stats'] = [{k: r[k] for k in ('Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage')}
+                               for r in rows[:14]]
+    # dominant kernel launches in the trace: the ConvLSTM K=36000 convs are the longest conv_igemm<.,2,2> launches
+    tr = find(os.path.join(src, 'trace'), '*kernel_trace.csv')
+    if tr:
+        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm_kernel' in r['Kernel_Name']]
+        by_grid = {}
+        for r in rows:
+            key = (r['Kernel_Name'][:60], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
+            dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            by_grid.setdefault(key, []).append(dur)
+        top = sorted(by_grid.items(), key=lambda kv: -sum(kv[1]))[:8]
+        lines.append('')
+        lines.append('| conv_igemm launch shape (grid threads x,y,z) | launches | avg us | total ms |')
+        lines.append('|---|---|---|---|')
+        for key, durs in top:
+            lines.append('| %s grid=(%s,%s,%s) | %d | %.1f | %.2f |' % (key[0], key[1], key[2], key[3], len(durs),
+                         sum(durs) / len(durs), sum(durs) / 1e3))
+        out['conv_igemm_by_grid'] = [{'grid': k[1:], 'n': len(v), 'avg_us': sum(v) / len(v)} for k, v in top]
+    pm = {}
+    for name in ('fetch', 'write'):
+        f = find(os.path.join(src, name), '*counter_collection.csv')
+        if not f:
+            continue
+        rows = [r for r in csv.DictReader(open(f)) if 'conv_igemm_kernel' in r['Kernel_Name']]
+        by = {}
+        for r in rows:
+            key = (r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size', ''), r.get('Grid_Size_Y', ''),
+                   r.get('Grid_Size_Z', ''))
+            by.setdefault(key, []).append(float(r['Counter_Value']))
+        pm[name] = by
+    if 'fetch' in pm and 'write' in pm:
+        # largest-traffic grid = the dominant ConvLSTM conv
+        key = max(pm['fetch'], key=lambda k: sum(pm['fetch'][k]))
+        fe = sum(pm['fetch'][key]) / len(pm['fetch'][key])
+        wr = sum(pm['write'].get(key, [0])) / max(1, len(pm['write'].get(key, [0])))
+        traffic = (2 * fe + wr) * 1024
+        out['dominant_grid'] = key
+        out['FETCH_SIZE_KiB_per_launch'] = fe
+        out['WRITE_SIZE_KiB_per_launch'] = wr
+        out['conv_igemm_clstm_bytes_per_launch'] = traffic
+        lines.append('')
+        lines.append('Dominant conv_igemm launch (grid %s): FETCH_SIZE %.0f KiB, WRITE_SIZE %.0f KiB per launch -> '
+                     'HBM traffic (2*FETCH + WRITE)*1024 = %.1f MB per launch' % (key, fe, wr, traffic / 1e6))
+    os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
+    json.dump(out, open(dst + '.json', 'w'), indent=1)
+    open(dst + '.md', 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+
+
+if __name__ == '__main__':
+    main()
