@@ -29,6 +29,8 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in VGPRs (HIP's uint4 struct
+                                                                   // kept one staging set in scratch memory)
 
 struct ConvK {
     const unsigned char* in;
@@ -40,28 +42,34 @@ struct ConvK {
     int n_img, h_in, w_in, c_in, pix_stride, kh, kw, sy, sx, h_out, w_out, c_out;
     int pad_mode, pad, ld_out, out_coff, ld_res, relu, splits;
     int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
+    int nt, mt, m_fast;
 };
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPC = 4; };      // elements per 16-byte chunk
 template <> struct Elem<bf16_raw> { static constexpr int EPC = 8; };
 
+// 16 zero bytes in device memory: invalid tile rows (m >= M) and the K tail (c >= c_in)
+// load from here, so the select happens on the ADDRESS before the load and nothing has
+// to wait for the loaded data until the ds_write that consumes it.
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
 __device__ __forceinline__ int lds_swz(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
 template <typename T>
-__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& a, const uint4& b);
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& a, const u32x4& b);
 
 template <>
-__device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& a, const uint4& b) {
+__device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 template <>
-__device__ __forceinline__ void mma_chunk<bf16_raw>(f32x4& acc, const uint4& a, const uint4& b) {
+__device__ __forceinline__ void mma_chunk<bf16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
                                                   0, 0, 0);
 }
@@ -91,7 +99,7 @@ __device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
 }
 
 template <typename T, int WN, int WM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     constexpr int BN = WN * 64, BM = WM * 64;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
@@ -101,41 +109,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, split = blockIdx.z;
+    // ---- XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs
+    // (each with a private 4 MiB L2): give every XCD a CONTIGUOUS range of work items
+    // and order the items so that neighbours share an operand panel.  m_fast: the
+    // m-tiles of one (n-tile, split) are adjacent -> the weight panel is fetched from
+    // HBM once per XCD and re-read from L2 (ConvLSTM: weights >> activations);
+    // otherwise n-tiles are adjacent -> the activation panel is shared (ResNet).
+    // Placement only affects speed, never results (bijective map, any placement valid).
+    int n0, m0, split;
+    {
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int nt_i, mt_i;
+        if (p.m_fast) {
+            mt_i = w % p.mt;
+            const int rest = w / p.mt;
+            nt_i = rest % p.nt;
+            split = rest / p.nt;
+        } else {
+            nt_i = w % p.nt;
+            const int rest = w / p.nt;
+            mt_i = rest % p.mt;
+            split = rest / p.mt;
+        }
+        n0 = nt_i * BN;
+        m0 = mt_i * BM;
+    }
     const int chunk = tid & 7, row0 = tid >> 3;
 
-    // ---- per-thread activation rows: decode (image, oy*sy, ox*sx) once
-    int rimg[B_PASSES], rpos[B_PASSES], roff[B_PASSES];
-#pragma unroll
-    for (int pb = 0; pb < B_PASSES; ++pb) {
-        const int m = m0 + row0 + 32 * pb;
-        if (m < p.M) {
-            const int img = m / p.hw_out, rem = m - img * p.hw_out;
-            const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
-            rimg[pb] = img;
-            rpos[pb] = ((oy * p.sy) << 16) | (ox * p.sx);
-        } else {
-            rimg[pb] = -1;
-            rpos[pb] = 0;
-        }
-        roff[pb] = -1;
-    }
+    // ---- per-thread activation rows.  Only the current element offset of each row is
+    // kept in registers; (image, oy, ox) is re-derived from m when the tap changes
+    // (kh*kw times per kernel) to keep the K loop's register budget for the pipeline.
+    int roff[B_PASSES];
     const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
-    auto set_tap = [&](int tap) {
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
 #pragma unroll
         for (int pb = 0; pb < B_PASSES; ++pb) {
-            if (rimg[pb] >= 0) {
-                const int py = (rpos[pb] >> 16) + ky, px = (rpos[pb] & 0xffff) + kx;
+            const int m = m0 + row0 + 32 * pb;
+            int off = -1;
+            if (m < p.M) {
+                const int img = m / p.hw_out, rem = m - img * p.hw_out;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                const int py = oy * p.sy + ky, px = ox * p.sx + kx;
                 int pix;
                 if (p.pad_mode) {
-                    const int grp = rimg[pb] / 6, f = rimg[pb] - grp * 6;
+                    const int grp = img / 6, f = img - grp * 6;
                     pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
                 } else {
-                    pix = (rimg[pb] * p.h_in + py) * p.w_in + px;
+                    pix = (img * p.h_in + py) * p.w_in + px;
                 }
-                roff[pb] = pix * p.pix_stride;
+                off = pix * p.pix_stride;
             }
+            roff[pb] = off;
         }
     };
 
@@ -145,38 +172,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     int c0 = (s_begin - tap * p.steps_per_tap) * BK;
 
     const T* in = reinterpret_cast<const T*>(p.in);
-    const T* wrow[A_PASSES];
-#pragma unroll
-    for (int pa = 0; pa < A_PASSES; ++pa)
-        wrow[pa] = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + row0 + 32 * pa) * p.k_total + chunk * EPC;
+    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + row0) * p.k_total + chunk * EPC;
+    const size_t wpass = (size_t)32 * p.k_total;       // 32 tile rows further down
 
-    uint4 ra[A_PASSES], rb[B_PASSES];
-    auto gload = [&]() {
-        const int e = c0 + chunk * EPC;
-        const size_t koff = (size_t)tap * p.c_pad + c0;
-#pragma unroll
-        for (int pa = 0; pa < A_PASSES; ++pa) ra[pa] = *reinterpret_cast<const uint4*>(wrow[pa] + koff);
-        // unconditional loads (invalid rows / K tail read element 0 and are zeroed by a
-        // select): no exec-mask branches in the K loop
-        const bool kval = e < p.c_in;
-#pragma unroll
-        for (int pb = 0; pb < B_PASSES; ++pb) {
-            const bool ok = kval && roff[pb] >= 0;
-            const uint4 t = *reinterpret_cast<const uint4*>(in + (ok ? (size_t)roff[pb] + e : (size_t)0));
-            rb[pb] = ok ? t : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto lds_store = [&](int buf) {
-        unsigned char* As = lds + buf * STAGE;
-        unsigned char* Bs = As + BN * 128;
-#pragma unroll
-        for (int pa = 0; pa < A_PASSES; ++pa)
-            *reinterpret_cast<uint4*>(As + lds_swz(row0 + 32 * pa, chunk)) = ra[pa];
-#pragma unroll
-        for (int pb = 0; pb < B_PASSES; ++pb)
-            *reinterpret_cast<uint4*>(Bs + lds_swz(row0 + 32 * pb, chunk)) = rb[pb];
-    };
-    auto advance = [&]() {
+    // two register sets: the loads of K step s+2 are issued while step s is computed and
+    // step s+1 (issued one iteration earlier) waits in the other set -> a weight line has
+    // more than one full MFMA phase to arrive from HBM before its ds_write needs it
+    u32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
+    // (macros, not lambdas taking array references: those kept the sets in scratch memory)
+#define CP360_GLOAD(RA, RB)                                                                              \
+    {                                                                                                    \
+        const int e_ = c0 + chunk * EPC;                                                                 \
+        const size_t koff_ = (size_t)tap * p.c_pad + c0;                                                 \
+        _Pragma("unroll") for (int pa = 0; pa < A_PASSES; ++pa)                                          \
+            RA[pa] = *reinterpret_cast<const u32x4*>(wbase + pa * wpass + koff_);                        \
+        const bool kval_ = e_ < p.c_in;                                                                  \
+        _Pragma("unroll") for (int pb = 0; pb < B_PASSES; ++pb) {                                        \
+            const bool ok_ = kval_ && roff[pb] >= 0;                                                     \
+            const T* src_ = ok_ ? in + (size_t)roff[pb] + e_ : reinterpret_cast<const T*>(g_zero16);     \
+            RB[pb] = *reinterpret_cast<const u32x4*>(src_);                                              \
+        }                                                                                                \
+    }
+#define CP360_LDS_STORE(BUF, RA, RB)                                                                     \
+    {                                                                                                    \
+        unsigned char* As_ = lds + (BUF) * STAGE;                                                        \
+        unsigned char* Bs_ = As_ + BN * 128;                                                             \
+        _Pragma("unroll") for (int pa = 0; pa < A_PASSES; ++pa)                                          \
+            *reinterpret_cast<u32x4*>(As_ + lds_swz(row0 + 32 * pa, chunk)) = RA[pa];                    \
+        _Pragma("unroll") for (int pb = 0; pb < B_PASSES; ++pb)                                          \
+            *reinterpret_cast<u32x4*>(Bs_ + lds_swz(row0 + 32 * pb, chunk)) = RB[pb];                    \
+    }
+    auto advance = [&]() __attribute__((always_inline)) {
         c0 += BK;
         if (c0 >= p.c_pad) {
             c0 = 0;
@@ -191,40 +217,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (s_begin < s_end) {
-        set_tap(tap);
-        gload();
-        lds_store(0);
-        __syncthreads();
+    const int nloc = s_end - s_begin;
+    if (nloc > 0) {
         const int lrow = lane & 15, lchunk = lane >> 4;
-        for (int s = s_begin; s < s_end; ++s) {
-            const int buf = (s - s_begin) & 1;
-            const bool more = (s + 1) < s_end;
-            if (more) {
-                advance();
-                gload();
-            }
+        auto compute = [&](int buf) __attribute__((always_inline)) {
             const unsigned char* As = lds + buf * STAGE;
             const unsigned char* Bs = As + BN * 128;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                uint4 a[4], b[4];
+                u32x4 a[4], b[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    a[i] = *reinterpret_cast<const uint4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk));
+                    a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk));
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    b[j] = *reinterpret_cast<const uint4*>(Bs + lds_swz(wm * 64 + j * 16 + lrow, kk * 4 + lchunk));
+                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * 64 + j * 16 + lrow, kk * 4 + lchunk));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
             }
-            if (more) lds_store(buf ^ 1);
+        };
+        set_tap(tap);
+        CP360_GLOAD(ra0, rb0);                       // step 0
+        if (nloc > 1) {
+            advance();
+            CP360_GLOAD(ra1, rb1);                   // step 1
+        }
+        CP360_LDS_STORE(0, ra0, rb0);
+        __syncthreads();
+        int it = 0;
+        while (true) {
+            // even step: compute LDS buffer 0; set 1 holds step it+1; set 0 is free
+            if (it + 2 < nloc) {
+                advance();
+                CP360_GLOAD(ra0, rb0);
+            }
+            compute(0);
+            if (it + 1 < nloc) CP360_LDS_STORE(1, ra1, rb1);
             __syncthreads();
+            if (++it >= nloc) break;
+            // odd step: compute LDS buffer 1; set 0 holds step it+1; set 1 is free
+            if (it + 2 < nloc) {
+                advance();
+                CP360_GLOAD(ra1, rb1);
+            }
+            compute(1);
+            if (it + 1 < nloc) CP360_LDS_STORE(0, ra0, rb0);
+            __syncthreads();
+            if (++it >= nloc) break;
         }
     }
 
+#undef CP360_GLOAD
+#undef CP360_LDS_STORE
     // ---- epilogue: lane holds channels n..n+3 of pixel m for every (i, j) sub-tile
     const int nl = (lane >> 4) * 4, ml = lane & 15;
 #pragma unroll
@@ -429,8 +475,12 @@ extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_
 }
 
 template <typename T, int WN, int WM>
-static void launch_conv(const ConvK& k, hipStream_t st) {
-    dim3 grid((k.c_out + WN * 64 - 1) / (WN * 64), (k.M + WM * 64 - 1) / (WM * 64), k.splits);
+static void launch_conv(ConvK& k, hipStream_t st) {
+    k.nt = (k.c_out + WN * 64 - 1) / (WN * 64);
+    k.mt = (k.M + WM * 64 - 1) / (WM * 64);
+    // share whichever operand panel is larger through the XCD's L2
+    k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
+    dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
     hipLaunchKernelGGL((conv_igemm_kernel<T, WN, WM>), grid, dim3(256), 0, st, k);
 }
 
