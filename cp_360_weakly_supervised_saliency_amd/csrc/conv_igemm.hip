@@ -304,6 +304,208 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     }
 }
 
+// ------------------------------------------------------------------ wide-tile LDS-DMA kernel
+// For c_out >= 256 (ConvLSTM, layers 2-4, CAM): 256 (channels) x 128 (pixels) tile, 8 waves
+// (4 x 2, each 64 x 64), K step 128 bytes, THREE LDS stages (3 x 48 KiB) filled by LDS-DMA
+// (global_load_lds_dwordx4: global -> LDS with no VGPR staging).  A DMA wave-instruction
+// writes 1 KiB = 8 tile rows linearly (LDS address = M0 + lane*16), so the XOR swizzle of
+// the LDS image is applied on the SOURCE side: lane l, which lands in physical chunk l&7
+// of row r, fetches logical chunk (l&7) ^ ((r>>1)&7) - the same involution the ds_read side
+// applies.  The per-lane source address also carries the CubePad / im2col gather.
+// Pipeline (one barrier per K step): at step `it` a wave waits (counted vmcnt) for its own
+// DMA of step `it`, meets the barrier (everyone's step-`it` data has landed and everyone has
+// finished reading the buffer of step it-1), issues the DMA of step it+2 into that freed
+// buffer and computes step `it`: every HBM/L2 load has two full MFMA phases to arrive.
+// The DMA is issued from inline asm (the compiler would otherwise drain vmcnt(0) before
+// every ds_read); its completion is counted by hand: DMA_PER_STEP per thread per step.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
+    constexpr int BN = 256, BM = 128, NSTAGE = 3;
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BK = 8 * EPC;
+    constexpr int A_PASSES = BN / 64, B_PASSES = BM / 64;       // 64 tile rows per 512-thread pass
+    constexpr int DMA_PER_STEP = A_PASSES + B_PASSES;
+    constexpr int STAGE = (BN + BM) * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int n0, m0, split;
+    {
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int nt_i, mt_i;
+        if (p.m_fast) {
+            mt_i = w % p.mt;
+            const int rest = w / p.mt;
+            nt_i = rest % p.nt;
+            split = rest / p.nt;
+        } else {
+            nt_i = w % p.nt;
+            const int rest = w / p.nt;
+            mt_i = rest % p.mt;
+            split = rest / p.mt;
+        }
+        n0 = nt_i * BN;
+        m0 = mt_i * BM;
+    }
+    // DMA role of this lane: tile row (within a 64-row pass) and the logical chunk it fetches
+    const int drow = 8 * wave + (lane >> 3);
+    const int dchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);      // = (l&7) ^ ((row>>1)&7)
+
+    int roff[B_PASSES];
+    const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb) {
+            const int m = m0 + drow + 64 * pb;
+            int off = -1;
+            if (m < p.M) {
+                const int img = m / p.hw_out, rem = m - img * p.hw_out;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                const int py = oy * p.sy + ky, px = ox * p.sx + kx;
+                int pix;
+                if (p.pad_mode) {
+                    const int grp = img / 6, f = img - grp * 6;
+                    pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
+                } else {
+                    pix = (img * p.h_in + py) * p.w_in + px;
+                }
+                off = pix * p.pix_stride;
+            }
+            roff[pb] = off;
+        }
+    };
+
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    const int nloc = s_end - s_begin;
+    int tap = s_begin / p.steps_per_tap;
+    int c0 = (s_begin - tap * p.steps_per_tap) * BK;
+
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + drow) * p.k_total + dchunk * EPC;
+    const size_t wpass = (size_t)64 * p.k_total;
+    const unsigned lds_base = (unsigned)(size_t)lds;                 // LDS byte offset (low 32 bits of the flat address)
+    const unsigned lds_wave = lds_base + (unsigned)(8 * wave) * 128; // this wave's 1 KiB slot inside a 64-row pass
+
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
+        const size_t koff = (size_t)tap * p.c_pad + c0;
+#pragma unroll
+        for (int pa = 0; pa < A_PASSES; ++pa) glds16(wbase + pa * wpass + koff, sbase + pa * 64 * 128);
+        const int e = c0 + dchunk * EPC;
+        const bool kval = e < p.c_in;
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb) {
+            const bool ok = kval && roff[pb] >= 0;
+            const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
+            glds16(src, sbase + BN * 128 + pb * 64 * 128);
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        c0 += BK;
+        if (c0 >= p.c_pad) {
+            c0 = 0;
+            ++tap;
+            set_tap(tap);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nloc > 0) {
+        const int lrow = lane & 15, lchunk = lane >> 4;
+        set_tap(tap);
+        issue(0);                                   // step 0 -> stage 0
+        if (nloc > 1) {
+            advance();
+            issue(1);                               // step 1 -> stage 1
+        }
+        int stage = 0;                              // stage holding step `it`
+        for (int it = 0; it < nloc; ++it) {
+            // my DMA of step `it` has landed when at most the DMA of step it+1 is outstanding
+            if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP) : "memory");
+            else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < nloc) {
+                advance();
+                issue(stage == 0 ? 2 : stage - 1);  // the stage step it-1 used (= (it+2) % 3)
+            }
+            const unsigned char* As = lds + stage * STAGE;
+            const unsigned char* Bs = As + BN * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk));
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * 64 + j * 16 + lrow, kk * 4 + lchunk));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
+            }
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+    }
+
+    // ---- epilogue (same lane -> (4 channels, 1 pixel) map as the narrow kernel)
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + nl;
+        if (n >= p.c_out) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + ml;
+            if (m >= p.M) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.partial) {
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+            } else {
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (p.res) {
+                    float r[4];
+                    load4(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ld_res + n, r);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                store4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ld_out + p.out_coff + n, v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ split-K finish
 template <typename T>
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ partial, int splits,
@@ -444,7 +646,7 @@ static int check_desc(const cp360_conv_desc* d) {
 extern "C" size_t cp360_conv_packed_bytes(const cp360_conv_desc* d) {
     if (check_desc(d)) return 0;
     const int c_pad = round_up(d->c_in, bk_of(d->dtype));
-    return (size_t)round_up(d->c_out, 128) * d->kh * d->kw * c_pad * elem_bytes(d->dtype);
+    return (size_t)round_up(d->c_out, 256) * d->kh * d->kw * c_pad * elem_bytes(d->dtype);
 }
 
 extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
@@ -459,7 +661,7 @@ extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_
     if (!w_oihw || !packed) return CP360_ERR_NULL;
     if (stem_mode && !(d->kh == 7 && d->kw == 1 && d->c_in == 32)) return CP360_ERR_UNSUPPORTED;
     const int c_pad = round_up(d->c_in, bk_of(d->dtype));
-    const int c_out_pad = round_up(d->c_out, 128);
+    const int c_out_pad = round_up(d->c_out, 256);
     const long long total = (long long)c_out_pad * d->kh * d->kw * c_pad;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -513,7 +715,17 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     k.k_total = d->kh * d->kw * k.c_pad;
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = d->c_out <= 64;
-    if (d->dtype == CP360_F32) {
+    const bool wide = d->c_out >= 256;
+    if (wide) {
+        k.nt = (k.c_out + 255) / 256;
+        k.mt = (k.M + 127) / 128;
+        k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
+        dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
+        if (d->dtype == CP360_F32)
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<float>), grid, dim3(512), 0, st, k);
+        else
+            hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+    } else if (d->dtype == CP360_F32) {
         if (narrow) launch_conv<float, 1, 4>(k, st);
         else launch_conv<float, 2, 2>(k, st);
     } else {
