@@ -331,20 +331,36 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wav
         : "memory");
 }
 
+// 4-byte LDS-DMA into a never-read LDS scratch slot: a register-free "touch" that pulls a
+// cache line from HBM into the XCD's L2 ahead of the real 16-byte DMA of a later K step.
+__device__ __forceinline__ void glds_touch(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 template <typename T>
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     constexpr int BN = 256, BM = 128, NSTAGE = 3;
+    constexpr int PF_STEPS = 8;          // weight lines are touched into L2 this many K steps ahead
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int A_PASSES = BN / 64, B_PASSES = BM / 64;       // 64 tile rows per 512-thread pass
     constexpr int DMA_PER_STEP = A_PASSES + B_PASSES;
     constexpr int STAGE = (BN + BM) * 128;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE + 8 * 256];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
-    int n0, m0, split;
+    int n0, m0, split, mt_idx;
     {
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
         }
         n0 = nt_i * BN;
         m0 = mt_i * BM;
+        mt_idx = mt_i;
     }
     // DMA role of this lane: tile row (within a 64-row pass) and the logical chunk it fetches
     const int drow = 8 * wave + (lane >> 3);
@@ -427,6 +444,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
             set_tap(tap);
         }
     };
+    // ---- L2 prefetch of the weight stream.  With the m-fast mapping the mt workgroups that
+    // share a weight panel run in lock step on one XCD, so only nt*splits/... distinct HBM
+    // streams are in flight chip-wide and the 2-step LDS pipeline alone leaves the kernel
+    // bound by HBM latency.  Each thread therefore touches one 64-byte half line of the
+    // panel PF_STEPS ahead (row tid>>1, half tid&1); the sharing workgroups split the rows
+    // between them (row % share == my m-tile % share) so the panel is touched about once.
+    const int pf_share = min(p.mt, 8);
+    const bool pf_mine = p.m_fast && (((tid >> 1) % pf_share) == (mt_idx % pf_share));
+    const T* pf_row = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + (tid >> 1)) * p.k_total + (tid & 1) * (4 * EPC);
+    const unsigned pf_lds = __builtin_amdgcn_readfirstlane(lds_base + NSTAGE * STAGE + wave * 256);
+    // Always exactly ONE VMEM op per call (lanes with nothing to touch read the zero page),
+    // so the hand-counted vmcnt below stays exact for every wave.
+    auto touch = [&](int step) __attribute__((always_inline)) {      // step: absolute K step index
+        const int t = step / p.steps_per_tap;
+        const size_t koff = (size_t)t * p.c_pad + (size_t)(step - t * p.steps_per_tap) * BK;
+        const T* src = (step < s_end && pf_mine) ? pf_row + koff : reinterpret_cast<const T*>(g_zero16);
+        glds_touch(src, pf_lds);
+    };
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -437,20 +472,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     if (nloc > 0) {
         const int lrow = lane & 15, lchunk = lane >> 4;
         set_tap(tap);
+#pragma unroll 1
+        for (int s = 2; s < PF_STEPS; ++s) touch(s_begin + s);      // warm the first lines
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every DMA group is preceded by one touch: [touch, 6 x DMA] = DMA_PER_STEP + 1 ops
+        touch(s_begin + PF_STEPS);
         issue(0);                                   // step 0 -> stage 0
         if (nloc > 1) {
             advance();
+            touch(s_begin + 1 + PF_STEPS);
             issue(1);                               // step 1 -> stage 1
         }
         int stage = 0;                              // stage holding step `it`
         for (int it = 0; it < nloc; ++it) {
-            // my DMA of step `it` has landed when at most the DMA of step it+1 is outstanding
-            if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP) : "memory");
+            // my DMA of step `it` has landed when at most the [touch + DMA] group of step it+1
+            // is still outstanding
+            if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP + 1) : "memory");
             else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (it + 2 < nloc) {
                 advance();
+                touch(s_begin + it + 2 + PF_STEPS);
                 issue(stage == 0 ? 2 : stage - 1);  // the stage step it-1 used (= (it+2) % 3)
             }
             const unsigned char* As = lds + stage * STAGE;
