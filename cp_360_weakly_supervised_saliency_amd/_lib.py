@@ -19,7 +19,7 @@ OK = 0
 SYMBOLS = [
     'cp360_strerror', 'cp360_version', 'cp360_cubepad_table_host', 'cp360_cubepad_nchw',
     'cp360_cubepad_nhwc', 'cp360_nchw_to_nhwc', 'cp360_nhwc_to_nchw', 'cp360_equi2cube',
-    'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes',
+    'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits',
     'cp360_conv_pack_weights', 'cp360_conv_forward', 'cp360_conv_finish',
     'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_window_minmax',
     'cp360_window_normalize',
@@ -66,6 +66,7 @@ def lib():
     L.cp360_conv_packed_bytes.argtypes = [pd]
     L.cp360_conv_partial_bytes.restype = sz
     L.cp360_conv_partial_bytes.argtypes = [pd]
+    L.cp360_conv_suggest_splits.argtypes = [pd]
     L.cp360_conv_pack_weights.argtypes = [pd, vp, vp, vp, i, vp]
     L.cp360_conv_forward.argtypes = [pd, vp, vp, vp, vp, vp, vp, vp]
     L.cp360_conv_finish.argtypes = [pd, vp, vp, vp, vp, vp]

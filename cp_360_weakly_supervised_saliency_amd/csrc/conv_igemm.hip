@@ -346,9 +346,9 @@ __device__ __forceinline__ void glds_touch(const void* gsrc, unsigned lds_dst /*
         : "memory");
 }
 
-template <typename T>
+template <typename T, int MJ>      // MJ = 16-pixel sub-tiles per wave: 4 -> 256x128 tile, 3 LDS stages; 8 -> 256x256, 2 stages
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
-    constexpr int BN = 256, BM = 128, NSTAGE = 3;
+    constexpr int BN = 256, BM = 32 * MJ, NSTAGE = (MJ == 4) ? 3 : 2;
     constexpr int PF_STEPS = 8;          // weight lines are touched into L2 this many K steps ahead
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
@@ -463,11 +463,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
         glds_touch(src, pf_lds);
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][MJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nloc > 0) {
         const int lrow = lane & 15, lchunk = lane >> 4;
@@ -475,44 +475,45 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
 #pragma unroll 1
         for (int s = 2; s < PF_STEPS; ++s) touch(s_begin + s);      // warm the first lines
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // every DMA group is preceded by one touch: [touch, 6 x DMA] = DMA_PER_STEP + 1 ops
+        // every DMA group is preceded by one touch: [touch, DMA_PER_STEP x DMA]
         touch(s_begin + PF_STEPS);
         issue(0);                                   // step 0 -> stage 0
-        if (nloc > 1) {
+        if (NSTAGE == 3 && nloc > 1) {
             advance();
             touch(s_begin + 1 + PF_STEPS);
             issue(1);                               // step 1 -> stage 1
         }
         int stage = 0;                              // stage holding step `it`
         for (int it = 0; it < nloc; ++it) {
-            // my DMA of step `it` has landed when at most the [touch + DMA] group of step it+1
-            // is still outstanding
-            if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP + 1) : "memory");
-            else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // my DMA of step `it` has landed when only the groups of later steps (NSTAGE-2 of
+            // them in steady state) are still outstanding
+            if (NSTAGE == 3 && it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP + 1) : "memory");
+            else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (it + 2 < nloc) {
+            // refill the stage that step it-1 used (every wave is past its reads: barrier above)
+            if (it + NSTAGE - 1 < nloc) {
                 advance();
-                touch(s_begin + it + 2 + PF_STEPS);
-                issue(stage == 0 ? 2 : stage - 1);  // the stage step it-1 used (= (it+2) % 3)
+                touch(s_begin + it + NSTAGE - 1 + PF_STEPS);
+                issue(stage == 0 ? NSTAGE - 1 : stage - 1);
             }
             const unsigned char* As = lds + stage * STAGE;
             const unsigned char* Bs = As + BN * 128;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                u32x4 a[4], b[4];
+                u32x4 a[4], b[MJ];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk));
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * 64 + j * 16 + lrow, kk * 4 + lchunk));
+                for (int j = 0; j < MJ; ++j)
+                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, kk * 4 + lchunk));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
+                    for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
             }
-            stage = stage == 2 ? 0 : stage + 1;
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
     }
 
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
         const int n = n0 + wn * 64 + i * 16 + nl;
         if (n >= p.c_out) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + ml;
+        for (int j = 0; j < MJ; ++j) {
+            const int m = m0 + wm * (16 * MJ) + j * 16 + ml;
             if (m >= p.M) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
@@ -697,6 +698,44 @@ extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
     return (size_t)d->splits * d->n_img * d->h_out * d->w_out * d->c_out * sizeof(float);
 }
 
+// Tile geometry of a launch (must match cp360_conv_forward's dispatch).
+static void tile_of(const cp360_conv_desc* d, int* bn, int* bm, int* slots) {
+    const long long M = (long long)d->n_img * d->h_out * d->w_out;
+    if (d->c_out >= 256) {
+        const long long m256 = (M + 255) / 256 * 256LL, m128 = (M + 127) / 128 * 128LL;
+        *bn = 256;
+        *bm = ((double)m256 <= 1.10 * (double)m128) ? 256 : 128;
+        *slots = 256;                 // 8-wave workgroups, one per CU
+    } else if (d->c_out <= 64) {
+        *bn = 64; *bm = 256; *slots = 512;
+    } else {
+        *bn = 128; *bm = 128; *slots = 512;
+    }
+}
+
+// Split-K factor that balances the launch over the chip: workgroup count close to a
+// multiple of the resident slots, each extra split costing one more f32 slab round trip.
+extern "C" int cp360_conv_suggest_splits(const cp360_conv_desc* d) {
+    cp360_conv_desc t = *d;
+    t.splits = 1;
+    if (check_desc(&t)) return 1;
+    int bn, bm, slots;
+    tile_of(&t, &bn, &bm, &slots);
+    const long long M = (long long)t.n_img * t.h_out * t.w_out;
+    const long long wgs = ((t.c_out + bn - 1) / bn) * ((M + bm - 1) / bm);
+    const int nsteps = t.kh * t.kw * (round_up(t.c_in, bk_of(t.dtype)) / bk_of(t.dtype));
+    if (wgs >= 4LL * slots || nsteps < 16) return 1;
+    int best = 1;
+    double best_cost = 0;
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && nsteps / s < 8) break;
+        const long long tot = wgs * s;
+        const double cost = (double)((tot + slots - 1) / slots * slots) / (double)tot * (1.0 + 0.02 * (s - 1));
+        if (s == 1 || cost < best_cost - 1e-9) { best = s; best_cost = cost; }
+    }
+    return best;
+}
+
 extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const float* scale, void* packed,
                                        int stem_mode, void* stream) {
     int rc = check_desc(d);
@@ -760,14 +799,23 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     const bool narrow = d->c_out <= 64;
     const bool wide = d->c_out >= 256;
     if (wide) {
+        // 256x256 tiles carry 1.5x the flops per byte brought into the CU; use them unless the
+        // pixel count pads badly (small-M launches) - then 256x128
+        int bn_, bm_, slots_;
+        tile_of(d, &bn_, &bm_, &slots_);
+        const bool big = bm_ == 256;
+        const int bm = bm_;
         k.nt = (k.c_out + 255) / 256;
-        k.mt = (k.M + 127) / 128;
+        k.mt = (k.M + bm - 1) / bm;
         k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
         dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
-        if (d->dtype == CP360_F32)
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<float>), grid, dim3(512), 0, st, k);
-        else
-            hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+        if (d->dtype == CP360_F32) {
+            if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 8>), grid, dim3(512), 0, st, k);
+            else     hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 4>), grid, dim3(512), 0, st, k);
+        } else {
+            if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 8>), grid, dim3(512), 0, st, k);
+            else     hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 4>), grid, dim3(512), 0, st, k);
+        }
     } else if (d->dtype == CP360_F32) {
         if (narrow) launch_conv<float, 1, 4>(k, st);
         else launch_conv<float, 2, 2>(k, st);

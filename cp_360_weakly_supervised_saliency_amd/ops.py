@@ -146,26 +146,6 @@ def cube2equi(x, face_map, coord, layout='nchw', want_full=True, want_max=False)
 
 
 # ----------------------------------------------------------------------------- convolution
-def _choose_splits(M, c_out, nsteps, narrow):
-    """Split-K factor.  The chip runs 256 CUs x 2 resident workgroups (LDS-bound), so a
-    launch is balanced when its workgroup count is a multiple of 512 (or much larger).
-    Small-M GEMMs (ConvLSTM: M = 294*B, K = 18000..36000) get there by splitting K;
-    each extra split costs one more f32 slab of [M, c_out] written and re-read."""
-    bn, bm = (64, 256) if narrow else (128, 128)
-    wgs = math.ceil(c_out / bn) * math.ceil(M / bm)
-    if wgs >= 2048 or nsteps < 16:
-        return 1
-    best, best_cost = 1, None
-    for s in range(1, 33):
-        if s > 1 and nsteps // s < 8:
-            break
-        tot = wgs * s
-        cost = math.ceil(tot / 512) * 512 / tot * (1.0 + 0.02 * (s - 1))
-        if best_cost is None or cost < best_cost - 1e-9:
-            best, best_cost = s, cost
-    return best
-
-
 # Optional launch timer (bench.py installs one): an object with
 # ``wrap(tag, flops, fn)`` that brackets the conv_forward launch with HIP events on the
 # current stream.  None = no instrumentation (default).
@@ -205,6 +185,7 @@ class Conv:
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         check(lib().cp360_conv_pack_weights(C.byref(d), ptr(w), ptr(sc), ptr(self.packed), 1 if stem else 0, stream()))
         self._partial = None
+        self._splits_cache = {}
 
     def out_hw(self, h_in, w_in):
         p2 = 2 * self.pad
@@ -245,12 +226,16 @@ class Conv:
             raise ValueError("stem expects an NHWC4 input")
         h_out, w_out = self.out_hw(h_in, w_in)
         M = n_img * h_out * w_out
-        if splits is None:
-            splits = _choose_splits(M, self.c_out, self.nsteps(), self.c_out <= 64)
         ld_out = self.c_out if out is None else out.shape[3]
         ld_res = 0 if residual is None else residual.shape[3]
-        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res)
         L = lib()
+        if splits is None:
+            key = (n_img, h_in, w_in)
+            splits = self._splits_cache.get(key)
+            if splits is None:
+                splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1)))
+                self._splits_cache[key] = splits
+        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res)
         def forward(*a):
             if LAUNCH_TIMER is None:
                 return L.cp360_conv_forward(*a)

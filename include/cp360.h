@@ -148,6 +148,8 @@ typedef struct {
 
 /* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */
 size_t cp360_conv_packed_bytes(const cp360_conv_desc* d);
+/* Split-K factor (>= 1) that fills the 256 CUs for this geometry (d->splits ignored). */
+int cp360_conv_suggest_splits(const cp360_conv_desc* d);
 /* Bytes of split-K workspace (0 when splits == 1). */
 size_t cp360_conv_partial_bytes(const cp360_conv_desc* d);
 /* Pack OIHW f32 weights [c_out, c_in_w, kh_w, kw_w] times scale[c_out] (BatchNorm

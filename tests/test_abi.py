@@ -67,6 +67,7 @@ def test_conv_packed_size_and_desc_checks():
         setattr(d, k, v)
     # f32: K per tap padded to 32 -> 2016; rows padded to 128 -> 4096
     assert L.cp360_conv_packed_bytes(C.byref(d)) == 4096 * 9 * 2016 * 4
+    assert 1 <= L.cp360_conv_suggest_splits(C.byref(d)) <= 32
     d.dtype = 1   # bf16: K per tap padded to 64 -> 2048
     assert L.cp360_conv_packed_bytes(C.byref(d)) == 4096 * 9 * 2048 * 2
     d.n_img = 5

@@ -52,7 +52,6 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     ho = y.shape[1]
     flops = 2.0 * n_img * ho * ho * cout * cin * k * k
     M = n_img * ho * ho
-    from cp_360_weakly_supervised_saliency_amd.ops import _choose_splits
-    sp = _choose_splits(M, cout, conv.nsteps(), cout <= 64)
+    sp = list(conv._splits_cache.values())[0]
     print('%s M=%7d N=%4d K=%5d splits=%d  %8.3f ms  %7.1f TFLOP/s' % (name, M, cout, cin * k * k, sp, ms, flops / ms / 1e9),
           flush=True)
