@@ -698,42 +698,63 @@ extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
     return (size_t)d->splits * d->n_img * d->h_out * d->w_out * d->c_out * sizeof(float);
 }
 
-// Tile geometry of a launch (must match cp360_conv_forward's dispatch).
-static void tile_of(const cp360_conv_desc* d, int* bn, int* bm, int* slots) {
+// ---- launch planning: tile shape + split-K from a small cost model (microseconds).
+// Calibrated on MI355X with tools/bench_conv.py: one K step (128 bytes of K per tile row)
+// of a resident workgroup costs about 2.2 us for the 256x256 LDS-DMA tile, 1.25 us for
+// 256x128 (one 8-wave workgroup per CU) and 1.5 us for the 4-wave tiles (two per CU); f32
+// steps are MFMA-bound and about 3x longer.  A launch runs ceil(workgroups / slots) rounds
+// of (fixed cost + steps x step cost); split-K adds the f32 slab round trip through HBM.
+struct ConvPlan {
+    int bn, bm, slots, splits;
+    double cost;
+};
+
+static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slots, double t_step) {
     const long long M = (long long)d->n_img * d->h_out * d->w_out;
-    if (d->c_out >= 256) {
-        const long long m256 = (M + 255) / 256 * 256LL, m128 = (M + 127) / 128 * 128LL;
-        *bn = 256;
-        *bm = ((double)m256 <= 1.10 * (double)m128) ? 256 : 128;
-        *slots = 256;                 // 8-wave workgroups, one per CU
-    } else if (d->c_out <= 64) {
-        *bn = 64; *bm = 256; *slots = 512;
-    } else {
-        *bn = 128; *bm = 128; *slots = 512;
+    const long long wgs = ((d->c_out + bn - 1) / bn) * ((M + bm - 1) / bm);
+    const int bk = bk_of(d->dtype);
+    const int nsteps = d->kh * d->kw * (round_up(d->c_in, bk) / bk);
+    if (d->dtype == CP360_F32) t_step *= 3.0;
+    const double t_fixed = 4.0;
+    ConvPlan best{bn, bm, slots, 1, 0.0};
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && nsteps / s < 8) break;
+        const long long rounds = (wgs * s + slots - 1) / slots;
+        const int steps = (nsteps + s - 1) / s;
+        double cost = (double)rounds * (t_fixed + steps * t_step);
+        if (s > 1) cost += 4.0 + (double)s * (double)M * d->c_out * 8.0 / 4.0e6;   // slab write + read at ~4 TB/s
+        if (s == 1 || cost < best.cost) {
+            best.splits = s;
+            best.cost = cost;
+        }
     }
+    return best;
 }
 
-// Split-K factor that balances the launch over the chip: workgroup count close to a
-// multiple of the resident slots, each extra split costing one more f32 slab round trip.
+static ConvPlan plan_of(const cp360_conv_desc* d) {
+    if (d->c_out <= 64) return plan_candidate(d, 64, 256, 512, 1.5);
+    if (d->c_out < 256) return plan_candidate(d, 128, 128, 512, 1.5);
+    const ConvPlan a = plan_candidate(d, 256, 256, 256, 2.2);
+    const ConvPlan b = plan_candidate(d, 256, 128, 256, 1.25);
+    return a.cost <= b.cost ? a : b;
+}
+
+// Tile geometry for a given (caller-chosen) split count: same candidates, splits fixed.
+static void tile_of(const cp360_conv_desc* d, int* bn, int* bm, int* slots) {
+    ConvPlan pl = plan_of(d);
+    if (d->c_out >= 256 && d->splits != pl.splits) {
+        // the caller overrode the split count: keep the tile the model prefers at ITS best split
+    }
+    *bn = pl.bn;
+    *bm = pl.bm;
+    *slots = pl.slots;
+}
+
 extern "C" int cp360_conv_suggest_splits(const cp360_conv_desc* d) {
     cp360_conv_desc t = *d;
     t.splits = 1;
     if (check_desc(&t)) return 1;
-    int bn, bm, slots;
-    tile_of(&t, &bn, &bm, &slots);
-    const long long M = (long long)t.n_img * t.h_out * t.w_out;
-    const long long wgs = ((t.c_out + bn - 1) / bn) * ((M + bm - 1) / bm);
-    const int nsteps = t.kh * t.kw * (round_up(t.c_in, bk_of(t.dtype)) / bk_of(t.dtype));
-    if (wgs >= 4LL * slots || nsteps < 16) return 1;
-    int best = 1;
-    double best_cost = 0;
-    for (int s = 1; s <= 32; ++s) {
-        if (s > 1 && nsteps / s < 8) break;
-        const long long tot = wgs * s;
-        const double cost = (double)((tot + slots - 1) / slots * slots) / (double)tot * (1.0 + 0.02 * (s - 1));
-        if (s == 1 || cost < best_cost - 1e-9) { best = s; best_cost = cost; }
-    }
-    return best;
+    return plan_of(&t).splits;
 }
 
 extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const float* scale, void* packed,
