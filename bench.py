@@ -70,7 +70,9 @@ def cpu_baseline(H, W, cd, precision_note):
     cores for a bounded sample: ONE clip of 2 frames at the benchmark resolution through
     the whole path (static stage x2, ConvLSTM x2, cube->equi)."""
     from tests.parity_helpers import oracle_pipeline
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 32 threads: fastest setting measured on the GPU box's host (tools/cpu_threads_probe.py); using all
+    # 256 hardware threads of the EPYC host makes oneDNN ~100x slower on these small convolutions
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     rs = synth.resnet50_state(seed=1)
     cs = synth.clstm_state(seed=2)
     clip = synth.clip_u8(3, 2, H, W)

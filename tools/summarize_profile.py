@@ -38,7 +38,7 @@ def main():
     # dominant kernel launches in the trace: the ConvLSTM K=36000 convs are the longest conv_igemm<.,2,2> launches
     tr = find(os.path.join(src, 'trace'), '*kernel_trace.csv')
     if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm_kernel' in r['Kernel_Name']]
+        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm' in r['Kernel_Name']]
         by_grid = {}
         for r in rows:
             key = (r['Kernel_Name'][:60], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
@@ -57,7 +57,7 @@ def main():
         f = find(os.path.join(src, name), '*counter_collection.csv')
         if not f:
             continue
-        rows = [r for r in csv.DictReader(open(f)) if 'conv_igemm_kernel' in r['Kernel_Name']]
+        rows = [r for r in csv.DictReader(open(f)) if 'conv_igemm' in r['Kernel_Name']]
         by = {}
         for r in rows:
             key = (r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size', ''), r.get('Grid_Size_Y', ''),
