@@ -355,7 +355,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     constexpr int A_PASSES = BN / 64, B_PASSES = BM / 64;       // 64 tile rows per 512-thread pass
     constexpr int DMA_PER_STEP = A_PASSES + B_PASSES;
     constexpr int STAGE = (BN + BM) * 128;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE + 8 * 256];
+    constexpr int EPI_BYTES = BM * (BN / (sizeof(T) == 4 ? 2 : 1) * (int)sizeof(T) + 16);
+    constexpr int PIPE_BYTES = NSTAGE * STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[(PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES) + 8 * 256];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     const int pf_share = min(p.mt, 8);
     const bool pf_mine = p.m_fast && (((tid >> 1) % pf_share) == (mt_idx % pf_share));
     const T* pf_row = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + (tid >> 1)) * p.k_total + (tid & 1) * (4 * EPC);
-    const unsigned pf_lds = __builtin_amdgcn_readfirstlane(lds_base + NSTAGE * STAGE + wave * 256);
+    const unsigned pf_lds = __builtin_amdgcn_readfirstlane(lds_base + (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES) + wave * 256);
     // Always exactly ONE VMEM op per call (lanes with nothing to touch read the zero page),
     // so the hand-counted vmcnt below stays exact for every wave.
     auto touch = [&](int step) __attribute__((always_inline)) {      // step: absolute K step index
@@ -517,8 +519,78 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
         }
     }
 
-    // ---- epilogue (same lane -> (4 channels, 1 pixel) map as the narrow kernel)
+    // ---- epilogue.  A lane holds 4 consecutive channels of one pixel per MFMA tile: stored
+    // directly that is 8-byte (bf16) pieces 512 bytes apart - fine for the f32 split-K slabs,
+    // wasteful for the HBM-bound 1x1 convolutions of ResNet (output + residual dominate
+    // their traffic).  The normal path therefore goes through LDS (all pipeline stages are
+    // free now): (A) the residual tile is read with full-line 16-byte accesses into LDS,
+    // (B) every lane adds bias (+ its residual values from LDS), applies ReLU, rounds ONCE and
+    // writes its 4 channels back to the same LDS slot, (C) the tile leaves with full-line
+    // 16-byte stores.  f32 tiles (256 KiB) are done in two 128-channel halves.
     const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const bool lds_epi = !p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
+                         (p.ld_res % EPC == 0);
+    if (lds_epi) {
+        constexpr int NH = sizeof(T) == 4 ? 2 : 1;             // channel halves
+        constexpr int HC = BN / NH;                            // channels per half
+        constexpr int CPR = HC / EPC;                          // 16-byte chunks per tile row
+        constexpr int S = HC * (int)sizeof(T) + 16;            // LDS row stride (bytes), 16-byte aligned
+        const T* res = reinterpret_cast<const T*>(p.res);
+        T* outp = reinterpret_cast<T*>(p.out);
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) {
+            __syncthreads();                                   // previous users of the LDS are done
+            const int nh0 = n0 + h * HC;
+            if (res) {
+                for (int q = tid; q < BM * CPR; q += 512) {
+                    const int row = q / CPR, c = q - row * CPR;
+                    const int m = m0 + row, n = nh0 + c * EPC;
+                    if (m < p.M && n < p.c_out)
+                        *reinterpret_cast<u32x4*>(lds + row * S + c * 16) =
+                            *reinterpret_cast<const u32x4*>(res + (size_t)m * p.ld_res + n);
+                }
+                __syncthreads();
+            }
+            if ((wn * 64) / HC == h) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ncol = wn * 64 + i * 16 + nl - h * HC;       // channel inside this half
+                    const int n = nh0 + ncol;
+                    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && n < p.c_out) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
+                        bb[0] = t.x; bb[1] = t.y; bb[2] = t.z; bb[3] = t.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j) {
+                        const int row = wm * (16 * MJ) + j * 16 + ml;
+                        T* slot = reinterpret_cast<T*>(lds + row * S) + ncol;
+                        float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2],
+                                      acc[i][j][3] + bb[3]};
+                        if (res) {
+                            float r[4];
+                            load4(slot, r);
+                            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                        }
+                        if (p.relu) {
+                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                        }
+                        store4(slot, v);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int q = tid; q < BM * CPR; q += 512) {
+                const int row = q / CPR, c = q - row * CPR;
+                const int m = m0 + row, n = nh0 + c * EPC;
+                if (m < p.M && n < p.c_out)
+                    *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ld_out + p.out_coff + n) =
+                        *reinterpret_cast<const u32x4*>(lds + row * S + c * 16);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + nl;
