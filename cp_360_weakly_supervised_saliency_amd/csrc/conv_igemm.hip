@@ -98,6 +98,80 @@ __device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+// ------------------------------------------------------------------ epilogue through LDS
+// A lane holds 4 consecutive channels of one pixel per MFMA tile: stored directly that is
+// 8-byte (bf16) pieces a pixel stride apart - fine for the f32 split-K slabs, wasteful for
+// the HBM-bound 1x1 convolutions of ResNet whose traffic is output + residual.  The normal
+// path therefore goes through LDS (the pipeline buffers are free after the K loop):
+// (A) the residual tile is read with full-line 16-byte accesses into LDS, (B) every lane adds
+// bias (+ its residual values from LDS), applies ReLU, rounds ONCE and writes its 4 channels
+// back to the same LDS slot, (C) the tile leaves with full-line 16-byte stores.  Tiles that do
+// not fit the kernel's LDS are processed in two channel halves.
+template <typename T, int BN, int BM, int MJ, int NT, int LDS_BYTES>
+__device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds, f32x4 (&acc)[4][MJ], int n0, int m0,
+                                             int wn, int wm, int lane, int tid) {
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int NH = (BM * (BN * (int)sizeof(T) + 16) <= LDS_BYTES) ? 1 : 2;   // channel halves
+    constexpr int HC = BN / NH;                            // channels per half
+    constexpr int CPR = HC / EPC;                          // 16-byte chunks per tile row
+    constexpr int S = HC * (int)sizeof(T) + 16;            // LDS row stride (bytes), 16-byte aligned
+    static_assert(BM * S <= LDS_BYTES, "epilogue tile does not fit the LDS of this kernel");
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const T* res = reinterpret_cast<const T*>(p.res);
+    T* outp = reinterpret_cast<T*>(p.out);
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+        __syncthreads();                                   // previous users of the LDS are done
+        const int nh0 = n0 + h * HC;
+        if (res) {
+            for (int q = tid; q < BM * CPR; q += NT) {
+                const int row = q / CPR, c = q - row * CPR;
+                const int m = m0 + row, n = nh0 + c * EPC;
+                if (m < p.M && n < p.c_out)
+                    *reinterpret_cast<u32x4*>(lds + row * S + c * 16) =
+                        *reinterpret_cast<const u32x4*>(res + (size_t)m * p.ld_res + n);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cn = wn * 64 + i * 16;                   // tile channel of this MFMA row block
+            if (cn / HC != h) continue;                        // wave-uniform
+            const int ncol = cn + nl - h * HC;                 // channel inside this half
+            const int n = nh0 + ncol;
+            float bb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.c_out) {
+                const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
+                bb[0] = t.x; bb[1] = t.y; bb[2] = t.z; bb[3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                const int row = wm * (16 * MJ) + j * 16 + ml;
+                T* slot = reinterpret_cast<T*>(lds + row * S) + ncol;
+                float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2], acc[i][j][3] + bb[3]};
+                if (res) {
+                    float r[4];
+                    load4(slot, r);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                store4(slot, v);
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < BM * CPR; q += NT) {
+            const int row = q / CPR, c = q - row * CPR;
+            const int m = m0 + row, n = nh0 + c * EPC;
+            if (m < p.M && n < p.c_out)
+                *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ld_out + p.out_coff + n) =
+                    *reinterpret_cast<const u32x4*>(lds + row * S + c * 16);
+        }
+    }
+}
+
 template <typename T, int WN, int WM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     constexpr int BN = WN * 64, BM = WM * 64;
@@ -271,6 +345,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
 
 #undef CP360_GLOAD
 #undef CP360_LDS_STORE
+    // ---- epilogue: through LDS (full-line accesses) unless it is a split-K slab or misaligned
+    if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
+        (p.ld_res % EPC == 0)) {
+        epilogue_lds<T, BN, BM, 4, 256, 2 * STAGE>(p, lds, acc, n0, m0, wn, wm, lane, tid);
+        return;
+    }
     // ---- epilogue: lane holds channels n..n+3 of pixel m for every (i, j) sub-tile
     const int nl = (lane >> 4) * 4, ml = lane & 15;
 #pragma unroll
@@ -519,76 +599,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
         }
     }
 
-    // ---- epilogue.  A lane holds 4 consecutive channels of one pixel per MFMA tile: stored
-    // directly that is 8-byte (bf16) pieces 512 bytes apart - fine for the f32 split-K slabs,
-    // wasteful for the HBM-bound 1x1 convolutions of ResNet (output + residual dominate
-    // their traffic).  The normal path therefore goes through LDS (all pipeline stages are
-    // free now): (A) the residual tile is read with full-line 16-byte accesses into LDS,
-    // (B) every lane adds bias (+ its residual values from LDS), applies ReLU, rounds ONCE and
-    // writes its 4 channels back to the same LDS slot, (C) the tile leaves with full-line
-    // 16-byte stores.  f32 tiles (256 KiB) are done in two 128-channel halves.
+    // ---- epilogue: through LDS (full-line accesses) unless it is a split-K slab or misaligned
     const int nl = (lane >> 4) * 4, ml = lane & 15;
     const bool lds_epi = !p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
                          (p.ld_res % EPC == 0);
     if (lds_epi) {
-        constexpr int NH = sizeof(T) == 4 ? 2 : 1;             // channel halves
-        constexpr int HC = BN / NH;                            // channels per half
-        constexpr int CPR = HC / EPC;                          // 16-byte chunks per tile row
-        constexpr int S = HC * (int)sizeof(T) + 16;            // LDS row stride (bytes), 16-byte aligned
-        const T* res = reinterpret_cast<const T*>(p.res);
-        T* outp = reinterpret_cast<T*>(p.out);
-#pragma unroll 1
-        for (int h = 0; h < NH; ++h) {
-            __syncthreads();                                   // previous users of the LDS are done
-            const int nh0 = n0 + h * HC;
-            if (res) {
-                for (int q = tid; q < BM * CPR; q += 512) {
-                    const int row = q / CPR, c = q - row * CPR;
-                    const int m = m0 + row, n = nh0 + c * EPC;
-                    if (m < p.M && n < p.c_out)
-                        *reinterpret_cast<u32x4*>(lds + row * S + c * 16) =
-                            *reinterpret_cast<const u32x4*>(res + (size_t)m * p.ld_res + n);
-                }
-                __syncthreads();
-            }
-            if ((wn * 64) / HC == h) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ncol = wn * 64 + i * 16 + nl - h * HC;       // channel inside this half
-                    const int n = nh0 + ncol;
-                    float bb[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias && n < p.c_out) {
-                        const float4 t = *reinterpret_cast<const float4*>(p.bias + n);
-                        bb[0] = t.x; bb[1] = t.y; bb[2] = t.z; bb[3] = t.w;
-                    }
-#pragma unroll
-                    for (int j = 0; j < MJ; ++j) {
-                        const int row = wm * (16 * MJ) + j * 16 + ml;
-                        T* slot = reinterpret_cast<T*>(lds + row * S) + ncol;
-                        float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2],
-                                      acc[i][j][3] + bb[3]};
-                        if (res) {
-                            float r[4];
-                            load4(slot, r);
-                            v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-                        }
-                        if (p.relu) {
-                            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                        }
-                        store4(slot, v);
-                    }
-                }
-            }
-            __syncthreads();
-            for (int q = tid; q < BM * CPR; q += 512) {
-                const int row = q / CPR, c = q - row * CPR;
-                const int m = m0 + row, n = nh0 + c * EPC;
-                if (m < p.M && n < p.c_out)
-                    *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ld_out + p.out_coff + n) =
-                        *reinterpret_cast<const u32x4*>(lds + row * S + c * 16);
-            }
-        }
+        epilogue_lds<T, BN, BM, MJ, 512, (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES)>(p, lds, acc, n0, m0, wn, wm,
+                                                                                             lane, tid);
         return;
     }
 #pragma unroll
