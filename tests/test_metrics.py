@@ -37,12 +37,14 @@ def test_metric_sanity():
 
 
 @pytest.mark.gpu
-def test_bf16_auc_cc_gate_full_size():
-    """5-frame 960x1920 clip, cube 224, full-size networks: oracle (fp32 CPU) vs the HIP path
-    in fp32 and bf16.  Gate (north star): |dAUC-Judd| <= 1e-3 and |dCC| <= 1e-3."""
+@pytest.mark.parametrize('T', [5, 16])
+def test_bf16_auc_cc_gate_full_size(T):
+    """T-frame 960x1920 clip (T = 5: the reference's seq_len; 16: the benchmark's), cube 224,
+    full-size networks: oracle (fp32 CPU) vs the HIP path in fp32 and bf16.
+    Gate (north star): |dAUC-Judd| <= 1e-3 and |dCC| <= 1e-3."""
     from cp_360_weakly_supervised_saliency_amd.pipeline import SaliencyEngine
     from tests.parity_helpers import oracle_pipeline
-    H, W, cd, T = 960, 1920, 224, 5
+    H, W, cd = 960, 1920, 224
     rs = synth.resnet50_state(seed=1)
     cs = synth.clstm_state(seed=2)
     clip = synth.clip_u8(40, T, H, W)
