@@ -573,28 +573,37 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
             else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* As = lds + stage * STAGE;
+            const unsigned char* Bs = As + BN * 128;
+            // first half of the step's fragments go out BEFORE the DMA issue: the address
+            // arithmetic + 9 DMA instructions of the refill then run under the LDS latency
+            u32x4 a[4], b[MJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, lchunk));
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, lchunk));
             // refill the stage that step it-1 used (every wave is past its reads: barrier above)
             if (it + NSTAGE - 1 < nloc) {
                 advance();
                 touch(s_begin + it + NSTAGE - 1 + PF_STEPS);
                 issue(stage == 0 ? NSTAGE - 1 : stage - 1);
             }
-            const unsigned char* As = lds + stage * STAGE;
-            const unsigned char* Bs = As + BN * 128;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4 a[4], b[MJ];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk));
+                for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
 #pragma unroll
-                for (int j = 0; j < MJ; ++j)
-                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, kk * 4 + lchunk));
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, 4 + lchunk));
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < MJ; ++j)
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, 4 + lchunk));
 #pragma unroll
-                    for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         }
     }
