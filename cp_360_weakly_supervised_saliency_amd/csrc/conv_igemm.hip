@@ -26,6 +26,7 @@
 //   bf16 path: v_mfma_f32_16x16x32_bf16 (a lane's 16-byte chunk = its 8 k-values).
 //   Split-K (gridDim.z) writes f32 partial slabs; conv_finish / lstm_gates reduce them.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -648,6 +649,201 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     }
 }
 
+// ------------------------------------------------------------------ 256x256 tile, 4-stage ring
+// Same tile and wave layout as conv_igemm_dma_kernel<T, 8>, but the K step is HALF a line
+// (64 bytes per tile row = one MFMA k-block) and the LDS holds a ring of FOUR 32 KiB stages:
+// the DMA of sub-step s+3 is issued at the start of sub-step s, so a load has three MFMA
+// phases (1.5 of the 2-stage kernel's steps) to arrive - the 2-stage kernel spent ~30 % of its
+// wave cycles in s_waitcnt/barrier (SQ_WAIT_ANY, profiles/).  A DMA wave-instruction now
+// covers 16 rows x 64 B; LDS rows are 64 B = 4 chunks, chunk c of row r stored at chunk
+// c ^ ((-(r >> 2)) & 3), which keeps every 16-lane ds_read_b128 group on 16 distinct 16-byte
+// slots of the 256-byte bank row (4 rows per bank row).
+__device__ __forceinline__ int lds_swz64(int row, int chunk) {
+    return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) {
+    constexpr int BN = 256, BM = 256, MJ = 8, NSTAGE = 4;
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BKS = 4 * EPC;                               // K elements per sub-step (64 bytes)
+    constexpr int A_PASSES = BN / 128, B_PASSES = BM / 128;     // 128 tile rows per 512-thread pass
+    constexpr int DMA_PER_STEP = A_PASSES + B_PASSES;           // 4
+    constexpr int STAGE = (BN + BM) * 64;                       // 32 KiB
+    constexpr int EPI_BYTES = BM * (BN / (sizeof(T) == 4 ? 2 : 1) * (int)sizeof(T) + 16);
+    constexpr int PIPE_BYTES = NSTAGE * STAGE;
+    constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int n0, m0, split;
+    {
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int nt_i, mt_i;
+        if (p.m_fast) {
+            mt_i = w % p.mt;
+            const int rest = w / p.mt;
+            nt_i = rest % p.nt;
+            split = rest / p.nt;
+        } else {
+            nt_i = w % p.nt;
+            const int rest = w / p.nt;
+            mt_i = rest % p.mt;
+            split = rest / p.mt;
+        }
+        n0 = nt_i * BN;
+        m0 = mt_i * BM;
+    }
+    // DMA role: 16 rows x 4 chunks per wave-instruction; lane l lands in row l>>2, physical
+    // chunk l&3 and therefore fetches logical chunk (l&3) ^ f(row), f = (-(row>>2)) & 3
+    const int drow = 16 * wave + (lane >> 2);                                  // row inside a 128-row pass
+    const int dchunk = (lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3); // ((drow>>2)&3) = (4*wave + (lane>>4)) & 3
+
+    int roff[B_PASSES];
+    const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb) {
+            const int m = m0 + drow + 128 * pb;
+            int off = -1;
+            if (m < p.M) {
+                const int img = m / p.hw_out, rem = m - img * p.hw_out;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                const int py = oy * p.sy + ky, px = ox * p.sx + kx;
+                int pix;
+                if (p.pad_mode) {
+                    const int grp = img / 6, f = img - grp * 6;
+                    pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
+                } else {
+                    pix = (img * p.h_in + py) * p.w_in + px;
+                }
+                off = pix * p.pix_stride;
+            }
+            roff[pb] = off;
+        }
+    };
+
+    // sub-step range of this split (two sub-steps per 128-byte K step of the packed layout)
+    const int s_begin = 2 * split * p.steps_per_split;
+    const int s_end = 2 * min(p.nsteps, (split + 1) * p.steps_per_split);
+    const int nloc = s_end - s_begin;
+    const int sub_per_tap = 2 * p.steps_per_tap;
+    int tap = s_begin / sub_per_tap;
+    int c0 = (s_begin - tap * sub_per_tap) * BKS;
+
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + drow) * p.k_total + dchunk * EPC;
+    const size_t wpass = (size_t)128 * p.k_total;
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;          // this wave's 1 KiB inside a pass
+
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
+        const size_t koff = (size_t)tap * p.c_pad + c0;
+#pragma unroll
+        for (int pa = 0; pa < A_PASSES; ++pa) glds16(wbase + pa * wpass + koff, sbase + pa * 128 * 64);
+        const int e = c0 + dchunk * EPC;
+        const bool kval = e < p.c_in;
+#pragma unroll
+        for (int pb = 0; pb < B_PASSES; ++pb) {
+            const bool ok = kval && roff[pb] >= 0;
+            const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
+            glds16(src, sbase + BN * 64 + pb * 128 * 64);
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        c0 += BKS;
+        if (c0 >= p.c_pad) {
+            c0 = 0;
+            ++tap;
+            set_tap(tap);
+        }
+    };
+
+    f32x4 acc[4][MJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nloc > 0) {
+        const int lrow = lane & 15, lchunk = lane >> 4;
+        set_tap(tap);
+        issue(0);
+        if (nloc > 1) { advance(); issue(1); }
+        if (nloc > 2) { advance(); issue(2); }
+        int stage = 0;
+        for (int it = 0; it < nloc; ++it) {
+            // DMA groups younger than sub-step `it`: min(2, nloc-1-it)
+            if (it + 2 < nloc)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_STEP) : "memory");
+            else if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP) : "memory");
+            else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* As = lds + stage * STAGE;
+            const unsigned char* Bs = As + BN * 64;
+            u32x4 a[4], b[MJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wn * 64 + i * 16 + lrow, lchunk));
+#pragma unroll
+            for (int j = 0; j < MJ; ++j)
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wm * (16 * MJ) + j * 16 + lrow, lchunk));
+            // refill the stage sub-step it-1 used (all waves are past their reads of it)
+            if (it + 3 < nloc) {
+                advance();
+                issue((stage + 3) & 3);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
+            stage = (stage + 1) & 3;
+        }
+    }
+
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
+        (p.ld_res % EPC == 0)) {
+        epilogue_lds<T, BN, BM, MJ, 512, LDS_BYTES>(p, lds, acc, n0, m0, wn, wm, lane, tid);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + nl;
+        if (n >= p.c_out) continue;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int m = m0 + wm * (16 * MJ) + j * 16 + ml;
+            if (m >= p.M) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.partial) {
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+            } else {
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (p.res) {
+                    float r[4];
+                    load4(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ld_res + n, r);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                store4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ld_out + p.out_coff + n, v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ split-K finish
 template <typename T>
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ partial, int splits,
@@ -928,12 +1124,18 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
         k.mt = (k.M + bm - 1) / bm;
         k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
         dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
+        static const int use_ring = []() {
+            const char* e = getenv("CP360_RING");           // A/B switch for tools/bench_conv.py
+            return e ? atoi(e) : 1;
+        }();
         if (d->dtype == CP360_F32) {
-            if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 8>), grid, dim3(512), 0, st, k);
-            else     hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 4>), grid, dim3(512), 0, st, k);
+            if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<float>), grid, dim3(512), 0, st, k);
+            else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 8>), grid, dim3(512), 0, st, k);
+            else          hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 4>), grid, dim3(512), 0, st, k);
         } else {
-            if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 8>), grid, dim3(512), 0, st, k);
-            else     hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 4>), grid, dim3(512), 0, st, k);
+            if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+            else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 8>), grid, dim3(512), 0, st, k);
+            else          hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 4>), grid, dim3(512), 0, st, k);
         }
     } else if (d->dtype == CP360_F32) {
         if (narrow) launch_conv<float, 1, 4>(k, st);
