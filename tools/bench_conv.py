@@ -15,6 +15,7 @@ ap.add_argument('--clips', type=int, default=4)
 ap.add_argument('--frames', type=int, default=64)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--only', default='')
+ap.add_argument('--splits', type=int, default=0)
 args = ap.parse_args()
 dt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
 dev = 'cuda'
@@ -40,18 +41,19 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     w = torch.randn(cout, cin, k, k) * (2.0 / (k * k * cin)) ** 0.5
     conv = ops.Conv(w, None, torch.zeros(cout), s, pad, True, dt, dev)
     x = torch.randn(n_img, n, n, cin, device=dev).to(dt)
-    y = conv(x)
+    kw = {'splits': args.splits} if args.splits else {}
+    y = conv(x, **kw)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(args.iters):
-        y = conv(x)
+        y = conv(x, **kw)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / args.iters
     ho = y.shape[1]
     flops = 2.0 * n_img * ho * ho * cout * cin * k * k
     M = n_img * ho * ho
-    sp = list(conv._splits_cache.values())[0]
+    sp = args.splits or list(conv._splits_cache.values())[0]
     print('%s M=%7d N=%4d K=%5d splits=%d  %8.3f ms  %7.1f TFLOP/s' % (name, M, cout, cin * k * k, sp, ms, flops / ms / 1e9),
           flush=True)
