@@ -742,19 +742,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     const unsigned lds_base = (unsigned)(size_t)lds;
     const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;          // this wave's 1 KiB inside a pass
 
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
-        const size_t koff = (size_t)tap * p.c_pad + c0;
-#pragma unroll
-        for (int pa = 0; pa < A_PASSES; ++pa) glds16(wbase + pa * wpass + koff, sbase + pa * 128 * 64);
-        const int e = c0 + dchunk * EPC;
-        const bool kval = e < p.c_in;
-#pragma unroll
-        for (int pb = 0; pb < B_PASSES; ++pb) {
-            const bool ok = kval && roff[pb] >= 0;
+    // DMA of one pass (q = 0,1: weight rows, 2,3: activation rows) of the CURRENT (tap, c0)
+    auto issue_one = [&](int q, unsigned sbase) __attribute__((always_inline)) {
+        if (q < A_PASSES) {
+            glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);
+        } else {
+            const int pb = q - A_PASSES;
+            const int e = c0 + dchunk * EPC;
+            const bool ok = e < p.c_in && roff[pb] >= 0;
             const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
             glds16(src, sbase + BN * 64 + pb * 128 * 64);
         }
+    };
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
+#pragma unroll
+        for (int q = 0; q < DMA_PER_STEP; ++q) issue_one(q, sbase);
     };
     auto advance = [&]() __attribute__((always_inline)) {
         c0 += BKS;
@@ -778,33 +781,46 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
         if (nloc > 1) { advance(); issue(1); }
         if (nloc > 2) { advance(); issue(2); }
         int stage = 0;
-        for (int it = 0; it < nloc; ++it) {
-            // DMA groups younger than sub-step `it`: min(2, nloc-1-it)
+        // One sub-step.  REFILL: the four DMA instructions that refill the stage freed by the
+        // barrier are spread between the four 8-MFMA groups (their address arithmetic and the
+        // SALU/M0 traffic then issue in the shadow of MFMAs instead of in front of them); the
+        // first one goes out under the latency of the fragment reads.
+#define CP360_RING_STEP(REFILL)                                                                            \
+        {                                                                                                  \
+            const unsigned char* As = lds + stage * STAGE;                                                 \
+            const unsigned char* Bs = As + BN * 64;                                                        \
+            u32x4 a[4], b[MJ];                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wn * 64 + i * 16 + lrow, lchunk));   \
+            _Pragma("unroll") for (int j = 0; j < MJ; ++j)                                                 \
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wm * (16 * MJ) + j * 16 + lrow, lchunk)); \
+            unsigned sbase = 0;                                                                            \
+            if (REFILL) {                                                                                  \
+                advance();                                                                                 \
+                sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)((stage + 3) & 3) * STAGE);    \
+            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+                if (REFILL) issue_one(i, sbase);                                                           \
+                _Pragma("unroll") for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);        \
+            }                                                                                              \
+            stage = (stage + 1) & 3;                                                                       \
+        }
+        int it = 0;
+        for (; it + 3 < nloc; ++it) {               // steady state: two younger DMA groups in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_STEP) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            CP360_RING_STEP(true)
+        }
+        for (; it < nloc; ++it) {                   // drain: no refill
             if (it + 2 < nloc)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_STEP) : "memory");
             else if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP) : "memory");
             else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* As = lds + stage * STAGE;
-            const unsigned char* Bs = As + BN * 64;
-            u32x4 a[4], b[MJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wn * 64 + i * 16 + lrow, lchunk));
-#pragma unroll
-            for (int j = 0; j < MJ; ++j)
-                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wm * (16 * MJ) + j * 16 + lrow, lchunk));
-            // refill the stage sub-step it-1 used (all waves are past their reads of it)
-            if (it + 3 < nloc) {
-                advance();
-                issue((stage + 3) & 3);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
-            stage = (stage + 1) & 3;
+            CP360_RING_STEP(false)
         }
+#undef CP360_RING_STEP
     }
 
     const int nl = (lane >> 4) * 4, ml = lane & 15;
