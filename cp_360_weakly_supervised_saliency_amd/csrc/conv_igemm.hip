@@ -412,25 +412,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wav
         : "memory");
 }
 
-// 4-byte LDS-DMA into a never-read LDS scratch slot: a register-free "touch" that pulls a
-// cache line from HBM into the XCD's L2 ahead of the real 16-byte DMA of a later K step.
-__device__ __forceinline__ void glds_touch(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dword %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-
 template <typename T, int MJ>      // MJ = 16-pixel sub-tiles per wave: 4 -> 256x128 tile, 3 LDS stages; 8 -> 256x256, 2 stages
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     constexpr int BN = 256, BM = 32 * MJ, NSTAGE = (MJ == 4) ? 3 : 2;
-    constexpr int PF_STEPS = 8;          // weight lines are touched into L2 this many K steps ahead
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     constexpr int A_PASSES = BN / 64, B_PASSES = BM / 64;       // 64 tile rows per 512-thread pass
@@ -438,12 +422,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     constexpr int STAGE = (BN + BM) * 128;
     constexpr int EPI_BYTES = BM * (BN / (sizeof(T) == 4 ? 2 : 1) * (int)sizeof(T) + 16);
     constexpr int PIPE_BYTES = NSTAGE * STAGE;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[(PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES) + 8 * 256];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[(PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES) ];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wm = wave & 1;
-    int n0, m0, split, mt_idx;
+    int n0, m0, split;
     {
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
@@ -462,7 +446,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
         }
         n0 = nt_i * BN;
         m0 = mt_i * BM;
-        mt_idx = mt_i;
     }
     // DMA role of this lane: tile row (within a 64-row pass) and the logical chunk it fetches
     const int drow = 8 * wave + (lane >> 3);
@@ -505,19 +488,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     const unsigned lds_base = (unsigned)(size_t)lds;                 // LDS byte offset (low 32 bits of the flat address)
     const unsigned lds_wave = lds_base + (unsigned)(8 * wave) * 128; // this wave's 1 KiB slot inside a 64-row pass
 
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
-        const size_t koff = (size_t)tap * p.c_pad + c0;
-#pragma unroll
-        for (int pa = 0; pa < A_PASSES; ++pa) glds16(wbase + pa * wpass + koff, sbase + pa * 64 * 128);
-        const int e = c0 + dchunk * EPC;
-        const bool kval = e < p.c_in;
-#pragma unroll
-        for (int pb = 0; pb < B_PASSES; ++pb) {
-            const bool ok = kval && roff[pb] >= 0;
+    // DMA of one 64-row pass (q < A_PASSES: weight rows, else activation rows) of the CURRENT (tap, c0)
+    auto issue_one = [&](int q, unsigned sbase) __attribute__((always_inline)) {
+        if (q < A_PASSES) {
+            glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 64 * 128);
+        } else {
+            const int pb = q - A_PASSES;
+            const int e = c0 + dchunk * EPC;
+            const bool ok = e < p.c_in && roff[pb] >= 0;
             const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
             glds16(src, sbase + BN * 128 + pb * 64 * 128);
         }
+    };
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
+#pragma unroll
+        for (int q = 0; q < DMA_PER_STEP; ++q) issue_one(q, sbase);
     };
     auto advance = [&]() __attribute__((always_inline)) {
         c0 += BK;
@@ -526,24 +512,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
             ++tap;
             set_tap(tap);
         }
-    };
-    // ---- L2 prefetch of the weight stream.  With the m-fast mapping the mt workgroups that
-    // share a weight panel run in lock step on one XCD, so only nt*splits/... distinct HBM
-    // streams are in flight chip-wide and the 2-step LDS pipeline alone leaves the kernel
-    // bound by HBM latency.  Each thread therefore touches one 64-byte half line of the
-    // panel PF_STEPS ahead (row tid>>1, half tid&1); the sharing workgroups split the rows
-    // between them (row % share == my m-tile % share) so the panel is touched about once.
-    const int pf_share = min(p.mt, 8);
-    const bool pf_mine = p.m_fast && (((tid >> 1) % pf_share) == (mt_idx % pf_share));
-    const T* pf_row = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + (tid >> 1)) * p.k_total + (tid & 1) * (4 * EPC);
-    const unsigned pf_lds = __builtin_amdgcn_readfirstlane(lds_base + (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES) + wave * 256);
-    // Always exactly ONE VMEM op per call (lanes with nothing to touch read the zero page),
-    // so the hand-counted vmcnt below stays exact for every wave.
-    auto touch = [&](int step) __attribute__((always_inline)) {      // step: absolute K step index
-        const int t = step / p.steps_per_tap;
-        const size_t koff = (size_t)t * p.c_pad + (size_t)(step - t * p.steps_per_tap) * BK;
-        const T* src = (step < s_end && pf_mine) ? pf_row + koff : reinterpret_cast<const T*>(g_zero16);
-        glds_touch(src, pf_lds);
     };
 
     f32x4 acc[4][MJ];
@@ -555,58 +523,53 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     if (nloc > 0) {
         const int lrow = lane & 15, lchunk = lane >> 4;
         set_tap(tap);
-#pragma unroll 1
-        for (int s = 2; s < PF_STEPS; ++s) touch(s_begin + s);      // warm the first lines
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // every DMA group is preceded by one touch: [touch, DMA_PER_STEP x DMA]
-        touch(s_begin + PF_STEPS);
         issue(0);                                   // step 0 -> stage 0
         if (NSTAGE == 3 && nloc > 1) {
             advance();
-            touch(s_begin + 1 + PF_STEPS);
             issue(1);                               // step 1 -> stage 1
         }
         int stage = 0;                              // stage holding step `it`
-        for (int it = 0; it < nloc; ++it) {
-            // my DMA of step `it` has landed when only the groups of later steps (NSTAGE-2 of
-            // them in steady state) are still outstanding
-            if (NSTAGE == 3 && it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP + 1) : "memory");
+        // One K step = 8 groups of MJ MFMAs (2 k-blocks x 4 channel blocks).  REFILL: the DMA
+        // instructions that refill the stage freed by the barrier are spread over the groups, so
+        // their address arithmetic / M0 traffic issues in the shadow of MFMAs; the first goes
+        // out under the latency of the first fragment reads.
+#define CP360_DMA_STEP(REFILL)                                                                             \
+        {                                                                                                  \
+            const unsigned char* As = lds + stage * STAGE;                                                 \
+            const unsigned char* Bs = As + BN * 128;                                                       \
+            unsigned sbase = 0;                                                                            \
+            u32x4 a[4], b[MJ];                                                                             \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                             \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+                    a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, kk * 4 + lchunk)); \
+                _Pragma("unroll") for (int j = 0; j < MJ; ++j)                                             \
+                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, kk * 4 + lchunk)); \
+                if (REFILL && kk == 0) {                                                                   \
+                    advance();                                                                             \
+                    sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)(stage == 0 ? NSTAGE - 1 : stage - 1) * STAGE); \
+                }                                                                                          \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+                    if (REFILL && kk * 4 + i < DMA_PER_STEP) issue_one(kk * 4 + i, sbase);                 \
+                    _Pragma("unroll") for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);    \
+                }                                                                                          \
+            }                                                                                              \
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;                                                   \
+        }
+        int it = 0;
+        for (; it + NSTAGE - 1 < nloc; ++it) {      // steady state: NSTAGE-2 younger DMA groups in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DMA_PER_STEP) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            CP360_DMA_STEP(true)
+        }
+        for (; it < nloc; ++it) {                   // drain: no refill
+            if (NSTAGE == 3 && it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP) : "memory");
             else                              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* As = lds + stage * STAGE;
-            const unsigned char* Bs = As + BN * 128;
-            // first half of the step's fragments go out BEFORE the DMA issue: the address
-            // arithmetic + 9 DMA instructions of the refill then run under the LDS latency
-            u32x4 a[4], b[MJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, lchunk));
-#pragma unroll
-            for (int j = 0; j < MJ; ++j)
-                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, lchunk));
-            // refill the stage that step it-1 used (every wave is past its reads: barrier above)
-            if (it + NSTAGE - 1 < nloc) {
-                advance();
-                touch(s_begin + it + NSTAGE - 1 + PF_STEPS);
-                issue(stage == 0 ? NSTAGE - 1 : stage - 1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 64 + i * 16 + lrow, 4 + lchunk));
-#pragma unroll
-            for (int j = 0; j < MJ; ++j)
-                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * (16 * MJ) + j * 16 + lrow, 4 + lchunk));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
-            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+            CP360_DMA_STEP(false)
         }
+#undef CP360_DMA_STEP
     }
 
     // ---- epilogue: through LDS (full-line accesses) unless it is a split-K slab or misaligned
