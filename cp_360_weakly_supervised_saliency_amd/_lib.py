@@ -72,8 +72,8 @@ def lib():
     L.cp360_conv_finish.argtypes = [pd, vp, vp, vp, vp, vp]
     L.cp360_cubepad_maxpool3s2.argtypes = [vp, vp, i, i, i, i, vp]
     L.cp360_lstm_gates.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, vp]
-    L.cp360_window_minmax.argtypes = [vp, vp, vp, i, sz, vp]
-    L.cp360_window_normalize.argtypes = [vp, vp, vp, i, i, i, vp, i, i, i, i, i, vp]
+    L.cp360_window_minmax.argtypes = [vp, vp, vp, i, sz, sz, vp]
+    L.cp360_window_normalize.argtypes = [vp, vp, vp, i, i, i, vp, i, i, i, i, i, sz, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     _lib = L

@@ -155,9 +155,9 @@ __device__ __forceinline__ void wave_minmax(float& mn, float& mx) {
 }
 
 __global__ __launch_bounds__(256) void minmax_pass1(const float* __restrict__ x, float* __restrict__ scratch,
-                                                    size_t per_clip) {
+                                                    size_t per_clip, size_t clip_stride) {
     const int b = blockIdx.y;
-    const float4* xv = reinterpret_cast<const float4*>(x + (size_t)b * per_clip);
+    const float4* xv = reinterpret_cast<const float4*>(x + (size_t)b * clip_stride);
     const size_t nv = per_clip / 4;
     float mn = INFINITY, mx = -INFINITY;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
@@ -210,12 +210,13 @@ __global__ __launch_bounds__(256) void minmax_pass2(const float* __restrict__ sc
 }
 
 extern "C" int cp360_window_minmax(const float* x, float* minmax, float* scratch, int B, size_t per_clip,
-                                   void* stream) {
+                                   size_t clip_stride, void* stream) {
     if (!x || !minmax || !scratch) return CP360_ERR_NULL;
     if (B <= 0 || per_clip == 0 || B > 65535) return CP360_ERR_BAD_SHAPE;
-    if (per_clip % 4 != 0) return CP360_ERR_ALIGN;
+    if (clip_stride == 0) clip_stride = per_clip;
+    if (per_clip % 4 != 0 || clip_stride % 4 != 0) return CP360_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(minmax_pass1, dim3(256, B), dim3(256), 0, st, x, scratch, per_clip);
+    hipLaunchKernelGGL(minmax_pass1, dim3(256, B), dim3(256), 0, st, x, scratch, per_clip, clip_stride);
     hipLaunchKernelGGL(minmax_pass2, dim3(B), dim3(256), 0, st, scratch, minmax, 256);
     CP360_CHECK_HIP();
     return CP360_OK;
@@ -225,14 +226,14 @@ extern "C" int cp360_window_minmax(const float* x, float* minmax, float* scratch
 template <typename T>
 __global__ __launch_bounds__(256) void window_normalize_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ minmax, T* __restrict__ y,
-                                                               int ld_y, int y_coff, float* __restrict__ y2, int T_,
-                                                               int t, int P, int C) {
+                                                               int ld_y, int y_coff, float* __restrict__ y2,
+                                                               size_t clip_stride, int t, int P, int C) {
     const int b = blockIdx.y;
     const float mn = minmax[b * 2], mx = minmax[b * 2 + 1];
     const float den = mx - mn;
     const int cq = C / 4;
     const long long total = (long long)P * cq;
-    const float* src = x + ((size_t)b * T_ + t) * P * C;
+    const float* src = x + (size_t)b * clip_stride + (size_t)t * P * C;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int pix = (int)(idx / cq), c = (int)(idx - (long long)pix * cq) * 4;
         const float4 v = *reinterpret_cast<const float4*>(src + (size_t)pix * C + c);
@@ -245,20 +246,22 @@ __global__ __launch_bounds__(256) void window_normalize_kernel(const float* __re
 }
 
 extern "C" int cp360_window_normalize(const float* x, const float* minmax, void* y, int y_dtype, int ld_y, int y_coff,
-                                      float* y2, int B, int T, int t, int P, int C, void* stream) {
+                                      float* y2, int B, int T, int t, int P, int C, size_t clip_stride,
+                                      void* stream) {
     if (!x || !minmax || !y) return CP360_ERR_NULL;
     if (B <= 0 || T <= 0 || t < 0 || t >= T || P <= 0 || C <= 0 || B > 65535) return CP360_ERR_BAD_SHAPE;
-    if (C % 4 != 0 || ld_y % 4 != 0 || y_coff % 4 != 0) return CP360_ERR_ALIGN;
+    if (clip_stride == 0) clip_stride = (size_t)T * P * C;
+    if (C % 4 != 0 || ld_y % 4 != 0 || y_coff % 4 != 0 || clip_stride % 4 != 0) return CP360_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)P * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (y_dtype == CP360_F32)
         hipLaunchKernelGGL((window_normalize_kernel<float>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
-                           (float*)y, ld_y, y_coff, y2, T, t, P, C);
+                           (float*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
     else if (y_dtype == CP360_BF16)
         hipLaunchKernelGGL((window_normalize_kernel<bf16_raw>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
-                           (bf16_raw*)y, ld_y, y_coff, y2, T, t, P, C);
+                           (bf16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

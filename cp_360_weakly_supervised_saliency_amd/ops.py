@@ -283,10 +283,10 @@ def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, H
                                  dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc, stream()))
 
 
-def window_minmax(x, B, per_clip, minmax, scratch):
-    check(lib().cp360_window_minmax(ptr(x), ptr(minmax), ptr(scratch), B, per_clip, stream()))
+def window_minmax(x, B, per_clip, minmax, scratch, clip_stride=0):
+    check(lib().cp360_window_minmax(ptr(x), ptr(minmax), ptr(scratch), B, per_clip, clip_stride, stream()))
 
 
-def window_normalize(x, minmax, y, y_coff, y2, B, T, t, P, Cc):
+def window_normalize(x, minmax, y, y_coff, y2, B, T, t, P, Cc, clip_stride=0):
     check(lib().cp360_window_normalize(ptr(x), ptr(minmax), ptr(y), dtype_code(y.dtype), y.shape[-1], y_coff,
-                                       ptr(y2), B, T, t, P, Cc, stream()))
+                                       ptr(y2), B, T, t, P, Cc, clip_stride, stream()))

@@ -26,19 +26,26 @@ class ClipRunner:
         self.minmax = torch.empty((self.B, 2), dtype=torch.float32, device=dev)
         self.scratch = torch.empty((self.B * 256 * 2,), dtype=torch.float32, device=dev)
 
-    def run(self, cam, return_hidden=False):
+    def run(self, cam, return_hidden=False, sliding=False):
         """cam: f32 [B, T, 6*w*w, C] (NHWC cube_feat of every frame of every window,
-        frame-major) on the device.  Returns saliency f32 [B, 2w, 4w]."""
+        frame-major) on the device.  Returns saliency f32 [B, 2w, 4w].
+
+        sliding=True: ``cam`` is ONE feature sequence [B+T-1, 6*w*w, C] and window b covers
+        frames b .. b+T-1 - the reference's stride-1 sliding window (test_temporal.py:57-65)
+        run as B windows in lock step without copying the overlapping frames."""
         B, T, P = self.B, self.T, self.P
         cin = self.cell.input_size
         if cin != self.cell.hidden_size:
             raise ValueError("hidden = cell = first frame needs input_size == hidden_size (test_temporal.py:70-73)")
-        ops.window_minmax(cam, B, T * P * cin, self.minmax, self.scratch)
+        if sliding and cam.shape[0] != B + T - 1:
+            raise ValueError("a sliding run over %d windows of %d frames needs %d frames" % (B, T, B + T - 1))
+        stride = P * cin if sliding else 0
+        ops.window_minmax(cam, B, T * P * cin, self.minmax, self.scratch, stride)
         # hidden = cell = (frame0 - mn) / (mx - mn)
-        ops.window_normalize(cam, self.minmax, self.xh, cin, self.c[0], B, T, 0, P, cin)
+        ops.window_normalize(cam, self.minmax, self.xh, cin, self.c[0], B, T, 0, P, cin, stride)
         cur = 0
         for t in range(T):
-            ops.window_normalize(cam, self.minmax, self.xh, 0, None, B, T, t, P, cin)
+            ops.window_normalize(cam, self.minmax, self.xh, 0, None, B, T, t, P, cin, stride)
             self.cell.step_nhwc(self.xh, self.c[cur], self.c[cur ^ 1],
                                 self.h_f32 if t == T - 1 else None, bufs=self.a)
             cur ^= 1

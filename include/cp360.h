@@ -187,14 +187,16 @@ int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias,
 /* ------------------------------------------------------------------ K7: window normalise
  * temporal_model/test_temporal.py:66-67,70-73,77: per clip min / max over the whole
  * window, then (x - mn) / (mx - mn).
- *   x [B, T, P, C] f32 (P = 6*w*w pixels, NHWC) ; minmax [B, 2] f32 (out) */
+ *   x: B windows of T frames, frame = [P, C] f32 (P = 6*w*w pixels, NHWC); window b starts
+ *   at x + b*clip_stride elements (0 = T*P*C, dense clips; P*C = the reference's stride-1
+ *   sliding window over one feature sequence, zero-copy) ; minmax [B, 2] f32 (out) */
 int cp360_window_minmax(const float* x, float* minmax, float* scratch /* [B*256*2] */,
-                        int B, size_t per_clip, void* stream);
+                        int B, size_t per_clip, size_t clip_stride, void* stream);
 /* y[b, p, y_coff + c] = (x[b, t, p, c] - mn_b) / (mx_b - mn_b); y has pixel stride ld_y
  * and dtype y_dtype; optional second destination y2 (f32, [B, P, C]) for the cell. */
 int cp360_window_normalize(const float* x, const float* minmax, void* y, int y_dtype,
                            int ld_y, int y_coff, float* y2, int B, int T, int t,
-                           int P, int C, void* stream);
+                           int P, int C, size_t clip_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -440,3 +440,39 @@ def test_pipeline_full_size_one_frame_fp32():
     got = ops.nhwc_to_nchw(score).cpu().numpy()
     mn, mx = want.min(), want.max()
     assert np.max(np.abs((got - mn) / (mx - mn) - (want - mn) / (mx - mn))) <= 1e-3
+
+
+def test_sliding_window_mode_equals_per_window(full_cell_state):
+    """The reference's stride-1 sliding window (test_temporal.py:57-65): B windows over ONE
+    feature sequence, run in lock step from overlapping memory, equal each window alone
+    and the oracle."""
+    cell = _full_cell(full_cell_state, 'fp32')
+    T, nwin = 3, 4
+    seq = synth.cam_clip(6200, T + nwin - 1)                                    # [F,6,1000,7,7]
+    pack = lambda f: np.ascontiguousarray(f.transpose(0, 1, 3, 4, 2)).reshape(f.shape[0], 294, 1000)
+    c2e = Cube2Equi(7)
+    sal = ClipRunner(cell, c2e, nwin, T).run(torch.from_numpy(pack(seq)).to(DEV), sliding=True).cpu().numpy()
+    single = ClipRunner(cell, c2e, 1, T)
+    sd = {k: torch.from_numpy(v) for k, v in full_cell_state.items()}
+    for b in range(nwin):
+        one = single.run(torch.from_numpy(pack(seq[b:b + T])[None]).to(DEV)).cpu().numpy()[0]
+        assert np.max(np.abs(sal[b] - one)) <= 2e-5
+    assert np.max(np.abs(sal[2] - o_clstm.window_saliency(seq[2:2 + T], sd))) <= 1e-3
+
+
+def test_pipeline_c5_shape_fp32():
+    """BASELINE config C5 geometry: 2048x4096 equirectangular, 6x512^2 cube faces, layer4 / ConvLSTM
+    at 16x16, saliency 32x64 - two frames, fp32, against the oracle."""
+    H, W, cd, T = 2048, 4096, 512, 2
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=2)
+    clip = synth.clip_u8(50, T, H, W)
+    ref, ref_cams, _ = ph.oracle_pipeline(clip, rs, cs, cd, return_all=True)
+    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision='fp32')
+    sal = eng(torch.from_numpy(clip[None]).to(DEV)).cpu().numpy()[0]
+    assert sal.shape == (32, 64) and ref.shape == (32, 64)
+    cam = eng.cam.cpu().numpy()[0]
+    want_cam = ref_cams.transpose(0, 1, 3, 4, 2).reshape(T, -1, 1000)
+    mn, mx = want_cam.min(), want_cam.max()
+    assert np.max(np.abs((cam - mn) / (mx - mn) - (want_cam - mn) / (mx - mn))) <= 1e-3
+    assert np.max(np.abs(sal - ref)) <= 1e-3
