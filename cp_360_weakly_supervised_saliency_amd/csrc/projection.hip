@@ -45,13 +45,34 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
         const bool y0ok = iy >= 0 && iy < H, y1ok = iy + 1 >= 0 && iy + 1 < H;
         const TI* base = equi + (size_t)fr * H * W * 3;
         float v[3];
+        if (sizeof(TI) == 1 && ix >= 0 && iy >= 0 && ix + 4 < W && iy + 1 < H) {
+            // u8 fast path: the two taps of a row are 6 adjacent bytes (HWC).  Instead of six byte
+            // loads per row: one 12-byte load from the enclosing 4-byte-aligned address and a funnel
+            // shift (ix + 4 < W keeps the 12 bytes inside the row).
+            auto row6 = [&](size_t byte_off) {
+                const size_t addr = (size_t)reinterpret_cast<const unsigned char*>(base) + byte_off;
+                const uint3 d = *reinterpret_cast<const uint3*>(addr & ~(size_t)3);
+                const unsigned sh = (unsigned)(addr & 3) * 8;
+                const unsigned long long lo = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
+                return sh ? (lo >> sh) | ((unsigned long long)d.z << (64 - sh)) : lo;
+            };
+            const size_t a0 = ((size_t)iy * W + ix) * 3;
+            const unsigned long long q0 = row6(a0), q1 = row6(a0 + (size_t)W * 3);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float t00 = (x0ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix) * 3 + c) : 0.f;
-            const float t01 = (x1ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix + 1) * 3 + c) : 0.f;
-            const float t10 = (x0ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix) * 3 + c) : 0.f;
-            const float t11 = (x1ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix + 1) * 3 + c) : 0.f;
-            v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+            for (int c = 0; c < 3; ++c) {
+                const float t00 = (float)((q0 >> (8 * c)) & 0xff), t01 = (float)((q0 >> (8 * (c + 3))) & 0xff);
+                const float t10 = (float)((q1 >> (8 * c)) & 0xff), t11 = (float)((q1 >> (8 * (c + 3))) & 0xff);
+                v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t00 = (x0ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix) * 3 + c) : 0.f;
+                const float t01 = (x1ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix + 1) * 3 + c) : 0.f;
+                const float t10 = (x0ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix) * 3 + c) : 0.f;
+                const float t11 = (x1ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix + 1) * 3 + c) : 0.f;
+                v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+            }
         }
         v[0] = (v[0] - m0) * s0;
         v[1] = (v[1] - m1) * s1;
