@@ -33,7 +33,7 @@ from cp_360_weakly_supervised_saliency_amd import ops                      # noq
 from cp_360_weakly_supervised_saliency_amd.pipeline import SaliencyEngine  # noqa: E402
 from cp_360_weakly_supervised_saliency_amd.utils import synth              # noqa: E402
 
-PEAK = {'bf16': 2500.0, 'fp32': 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 
 
 class LaunchTimer:
@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--precision', default=os.environ.get('CP360_PRECISION', 'bf16'), choices=['fp32', 'bf16'])
+    ap.add_argument('--precision', default=os.environ.get('CP360_PRECISION', 'bf16'), choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--clips', type=int, default=4, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=16, help='frames per clip')
     ap.add_argument('--equi', default='1024x2048')
@@ -165,7 +165,7 @@ def main():
             'value': round(frames_total / elapsed, 3), 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'C3/C4 per-GPU shard: %d clips x %d frames %dx%d u8 equi -> 6x%d^2 cube -> '
                                    'CubePad ResNet-50 -> CAM -> ConvLSTM x%d -> cube_to_equi saliency %dx%d'
                                    % (B, T, H, W, args.cube, T, 2 * eng.w, 4 * eng.w),

@@ -12,7 +12,17 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libcp360.so')
 
-F32, BF16, U8 = 0, 1, 3
+F32, BF16, F16, U8 = 0, 1, 2, 3
+
+# precision names accepted by the model wrappers -> torch dtype of activations / packed weights
+PRECISIONS = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}
+
+
+def precision_dtype(precision):
+    try:
+        return PRECISIONS[precision]
+    except KeyError:
+        raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
@@ -112,6 +122,8 @@ def dtype_code(dt):
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16
     if dt == torch.uint8:
         return U8
     raise ValueError("unsupported dtype %s" % dt)

@@ -12,6 +12,7 @@
     } while (0)
 
 typedef unsigned short bf16_raw;   // storage type of a bf16 element
+typedef _Float16 f16_raw;          // IEEE half: a distinct C++ type, so templates can tell it from bf16
 
 __device__ __forceinline__ float bf16_to_f32(bf16_raw v) {
     return __uint_as_float(((unsigned)v) << 16);

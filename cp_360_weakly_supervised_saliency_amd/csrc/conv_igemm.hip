@@ -30,6 +30,7 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in VGPRs (HIP's uint4 struct
                                                                    // kept one staging set in scratch memory)
 
@@ -49,6 +50,7 @@ struct ConvK {
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPC = 4; };      // elements per 16-byte chunk
 template <> struct Elem<bf16_raw> { static constexpr int EPC = 8; };
+template <> struct Elem<f16_raw> { static constexpr int EPC = 8; };
 
 // 16 zero bytes in device memory: invalid tile rows (m >= M) and the K tail (c >= c_in)
 // load from here, so the select happens on the ADDRESS before the load and nothing has
@@ -75,6 +77,12 @@ __device__ __forceinline__ void mma_chunk<bf16_raw>(f32x4& acc, const u32x4& a, 
                                                   0, 0, 0);
 }
 
+template <>
+__device__ __forceinline__ void mma_chunk<f16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0,
+                                                 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
 template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_as_f32<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
@@ -88,6 +96,16 @@ __device__ __forceinline__ void store4(bf16_raw* p, const float v[4]) {
     o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
     o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
     *reinterpret_cast<uint2*>(p) = o;
+}
+__device__ __forceinline__ void store4(f16_raw* p, const float v[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    const f16x4 o = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3]};
+    *reinterpret_cast<f16x4*>(p) = o;
+}
+__device__ __forceinline__ void load4(const f16_raw* p, float v[4]) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+    const f16x4 t = *reinterpret_cast<const f16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 __device__ __forceinline__ void load4(const float* p, float v[4]) {
     float4 t = *reinterpret_cast<const float4*>(p);
@@ -925,19 +943,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         }
         if constexpr (sizeof(T) == 4)
             packed[idx] = v;
+        else if constexpr (__is_same(T, f16_raw))
+            packed[idx] = (f16_raw)v;
         else
             packed[idx] = f32_to_bf16(v);
     }
 }
 
 // ------------------------------------------------------------------ host side
-static int elem_bytes(int dtype) { return dtype == CP360_F32 ? 4 : (dtype == CP360_BF16 ? 2 : 0); }
+static int elem_bytes(int dtype) { return dtype == CP360_F32 ? 4 : ((dtype == CP360_BF16 || dtype == CP360_F16) ? 2 : 0); }
 static int bk_of(int dtype) { return 128 / elem_bytes(dtype); }
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 static int check_desc(const cp360_conv_desc* d) {
     if (!d) return CP360_ERR_NULL;
-    if (d->dtype != CP360_F32 && d->dtype != CP360_BF16) return CP360_ERR_BAD_DTYPE;
+    if (d->dtype != CP360_F32 && d->dtype != CP360_BF16 && d->dtype != CP360_F16) return CP360_ERR_BAD_DTYPE;
     if (d->n_img <= 0 || d->h_in <= 0 || d->w_in <= 0 || d->c_in <= 0 || d->kh <= 0 || d->kw <= 0 || d->sy <= 0 ||
         d->sx <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_out <= 0 || d->splits < 1 || d->pix_stride <= 0)
         return CP360_ERR_BAD_SHAPE;
@@ -1045,6 +1065,9 @@ extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_
     if (d->dtype == CP360_F32)
         hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
                            (float*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
+    else if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((pack_weights_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
+                           (f16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
     else
         hipLaunchKernelGGL((pack_weights_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
                            (bf16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
@@ -1107,18 +1130,22 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
             const char* e = getenv("CP360_RING");           // A/B switch for tools/bench_conv.py
             return e ? atoi(e) : 1;
         }();
-        if (d->dtype == CP360_F32) {
-            if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<float>), grid, dim3(512), 0, st, k);
-            else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 8>), grid, dim3(512), 0, st, k);
-            else          hipLaunchKernelGGL((conv_igemm_dma_kernel<float, 4>), grid, dim3(512), 0, st, k);
-        } else {
-            if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
-            else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 8>), grid, dim3(512), 0, st, k);
-            else          hipLaunchKernelGGL((conv_igemm_dma_kernel<bf16_raw, 4>), grid, dim3(512), 0, st, k);
+#define CP360_WIDE(TT)                                                                                     \
+        {                                                                                                      \
+            if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT>), grid, dim3(512), 0, st, k);  \
+            else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 8>), grid, dim3(512), 0, st, k);       \
+            else          hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 4>), grid, dim3(512), 0, st, k);       \
         }
+        if (d->dtype == CP360_F32) CP360_WIDE(float)
+        else if (d->dtype == CP360_F16) CP360_WIDE(f16_raw)
+        else CP360_WIDE(bf16_raw)
+#undef CP360_WIDE
     } else if (d->dtype == CP360_F32) {
         if (narrow) launch_conv<float, 1, 4>(k, st);
         else launch_conv<float, 2, 2>(k, st);
+    } else if (d->dtype == CP360_F16) {
+        if (narrow) launch_conv<f16_raw, 1, 4>(k, st);
+        else launch_conv<f16_raw, 2, 2>(k, st);
     } else {
         if (narrow) launch_conv<bf16_raw, 1, 4>(k, st);
         else launch_conv<bf16_raw, 2, 2>(k, st);
@@ -1141,6 +1168,10 @@ extern "C" int cp360_conv_finish(const cp360_conv_desc* d, const float* partial,
         hipLaunchKernelGGL((conv_finish_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, partial, d->splits,
                            bias, (const float*)residual, d->ld_res, (float*)out, d->ld_out, d->out_coff, M, d->c_out,
                            d->relu);
+    else if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((conv_finish_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
+                           d->splits, bias, (const f16_raw*)residual, d->ld_res, (f16_raw*)out, d->ld_out,
+                           d->out_coff, M, d->c_out, d->relu);
     else
         hipLaunchKernelGGL((conv_finish_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
                            d->splits, bias, (const bf16_raw*)residual, d->ld_res, (bf16_raw*)out, d->ld_out,
@@ -1165,6 +1196,9 @@ extern "C" int cp360_lstm_gates(const float* gates_partial, int splits, const fl
     else if (h_dtype == CP360_BF16)
         hipLaunchKernelGGL((lstm_gates_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
                            splits, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc);
+    else if (h_dtype == CP360_F16)
+        hipLaunchKernelGGL((lstm_gates_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
+                           splits, bias, c_prev, c_next, (f16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

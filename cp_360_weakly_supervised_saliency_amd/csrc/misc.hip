@@ -8,6 +8,8 @@ template <> __device__ __forceinline__ float ld_f32<bf16_raw>(const bf16_raw* p)
 template <typename T> __device__ __forceinline__ void st_f32(T* p, float v);
 template <> __device__ __forceinline__ void st_f32<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st_f32<bf16_raw>(bf16_raw* p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ float ld_f32<f16_raw>(const f16_raw* p) { return (float)*p; }
+template <> __device__ __forceinline__ void st_f32<f16_raw>(f16_raw* p, float v) { *p = (f16_raw)v; }
 
 // ------------------------------------------------------------------ K3b
 // resnet_cubic.py:169-170: x = pad1(x); x = maxpool(x)  (3x3, stride 2, padding 0) on
@@ -61,6 +63,9 @@ extern "C" int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, i
     else if (dtype == CP360_BF16)
         hipLaunchKernelGGL((cubepad_maxpool_kernel<bf16_raw, 4>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const bf16_raw*)x, (bf16_raw*)y, n6, n, C, ho);
+    else if (dtype == CP360_F16)
+        hipLaunchKernelGGL((cubepad_maxpool_kernel<f16_raw, 4>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const f16_raw*)x, (f16_raw*)y, n6, n, C, ho);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();
@@ -108,18 +113,20 @@ static int transpose_dispatch(const void* x, void* y, int N, int R, int Cc, size
                               size_t ys_c, int in_dtype, int out_dtype, hipStream_t st) {
     if (!x || !y) return CP360_ERR_NULL;
     if (N <= 0 || R <= 0 || Cc <= 0 || N > 65535) return CP360_ERR_BAD_SHAPE;
-    if (in_dtype == CP360_F32 && out_dtype == CP360_F32)
-        return launch_transpose<float, float>(x, y, N, R, Cc, xs_n, xs_r, ys_n, ys_c, st);
-    if (in_dtype == CP360_F32 && out_dtype == CP360_BF16)
-        return launch_transpose<float, bf16_raw>(x, y, N, R, Cc, xs_n, xs_r, ys_n, ys_c, st);
-    if (in_dtype == CP360_BF16 && out_dtype == CP360_F32)
-        return launch_transpose<bf16_raw, float>(x, y, N, R, Cc, xs_n, xs_r, ys_n, ys_c, st);
-    if (in_dtype == CP360_BF16 && out_dtype == CP360_BF16)
-        return launch_transpose<bf16_raw, bf16_raw>(x, y, N, R, Cc, xs_n, xs_r, ys_n, ys_c, st);
+#define CP360_TR(DI, TI, DO, TO) \
+    if (in_dtype == DI && out_dtype == DO) return launch_transpose<TI, TO>(x, y, N, R, Cc, xs_n, xs_r, ys_n, ys_c, st);
+    CP360_TR(CP360_F32, float, CP360_F32, float)
+    CP360_TR(CP360_F32, float, CP360_BF16, bf16_raw)
+    CP360_TR(CP360_F32, float, CP360_F16, f16_raw)
+    CP360_TR(CP360_BF16, bf16_raw, CP360_F32, float)
+    CP360_TR(CP360_BF16, bf16_raw, CP360_BF16, bf16_raw)
+    CP360_TR(CP360_F16, f16_raw, CP360_F32, float)
+    CP360_TR(CP360_F16, f16_raw, CP360_F16, f16_raw)
+#undef CP360_TR
     return CP360_ERR_BAD_DTYPE;
 }
 
-static int elem_sz(int dtype) { return dtype == CP360_F32 ? 4 : (dtype == CP360_BF16 ? 2 : 0); }
+static int elem_sz(int dtype) { return dtype == CP360_F32 ? 4 : ((dtype == CP360_BF16 || dtype == CP360_F16) ? 2 : 0); }
 
 extern "C" int cp360_nchw_to_nhwc(const void* x, void* y, int N, int C, int H, int W, int in_dtype, int out_dtype,
                                   int ld_y, int y_coff, void* stream) {
@@ -262,6 +269,9 @@ extern "C" int cp360_window_normalize(const float* x, const float* minmax, void*
     else if (y_dtype == CP360_BF16)
         hipLaunchKernelGGL((window_normalize_kernel<bf16_raw>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
                            (bf16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
+    else if (y_dtype == CP360_F16)
+        hipLaunchKernelGGL((window_normalize_kernel<f16_raw>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
+                           (f16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

@@ -16,6 +16,11 @@ template <typename TI> __device__ __forceinline__ float px_load(const TI* p);
 template <> __device__ __forceinline__ float px_load<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float px_load<uint8_t>(const uint8_t* p) { return (float)*p; }
 
+template <typename TO> __device__ __forceinline__ TO out_cvt(float v);
+template <> __device__ __forceinline__ float out_cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_raw out_cvt<bf16_raw>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ f16_raw out_cvt<f16_raw>(float v) { return (f16_raw)v; }
+
 template <typename TI, typename TO, int LAYOUT, bool FIXED>
 __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ equi, const float2* __restrict__ grid,
                                                         TO* __restrict__ out, int F, int H, int W, int cd,
@@ -80,20 +85,16 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
         if (LAYOUT == 0) {   // [6F, 3, cd, cd]
             const int face = g / (cd * cd), pix = g - face * cd * cd;
             const size_t o = ((size_t)(fr * 6 + face) * 3) * cd * cd + pix;
-            if constexpr (sizeof(TO) == 4) {
-                out[o] = v[0]; out[o + (size_t)cd * cd] = v[1]; out[o + 2 * (size_t)cd * cd] = v[2];
-            } else {
-                out[o] = f32_to_bf16(v[0]); out[o + (size_t)cd * cd] = f32_to_bf16(v[1]);
-                out[o + 2 * (size_t)cd * cd] = f32_to_bf16(v[2]);
-            }
+            out[o] = out_cvt<TO>(v[0]);
+            out[o + (size_t)cd * cd] = out_cvt<TO>(v[1]);
+            out[o + 2 * (size_t)cd * cd] = out_cvt<TO>(v[2]);
         } else {             // [6F, cd, cd, 4]
             if constexpr (sizeof(TO) == 4) {
                 *reinterpret_cast<float4*>(out + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], 0.f);
             } else {
-                uint2 o;
-                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16(v[2]);
-                *reinterpret_cast<uint2*>(out + (size_t)idx * 4) = o;
+                typedef __attribute__((ext_vector_type(4))) TO vec4;
+                const vec4 o = {out_cvt<TO>(v[0]), out_cvt<TO>(v[1]), out_cvt<TO>(v[2]), out_cvt<TO>(0.f)};
+                *reinterpret_cast<vec4*>(out + (size_t)idx * 4) = o;
             }
         }
     }
@@ -134,6 +135,12 @@ extern "C" int cp360_equi2cube(const void* equi, const float* grid, void* out, i
     if (in_dtype == CP360_F32 && out_dtype == CP360_BF16)
         return launch_e2c<float, bf16_raw>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
                                            cv_fixed_point, st);
+    if (in_dtype == CP360_U8 && out_dtype == CP360_F16)
+        return launch_e2c<uint8_t, f16_raw>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
+                                            cv_fixed_point, st);
+    if (in_dtype == CP360_F32 && out_dtype == CP360_F16)
+        return launch_e2c<float, f16_raw>(equi, grid, out, F, H, W, cd, mean3_host, istd3_host, scale, out_layout,
+                                          cv_fixed_point, st);
     return CP360_ERR_BAD_DTYPE;
 }
 

@@ -11,12 +11,12 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .._lib import PRECISIONS as _DTYPES
 from .cube_pad import CubePad
 
 KERNEL_SIZE = 3
 PADDING = 0
 
-_DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
 
 
 def _stamp(module, extra=()):
@@ -46,7 +46,7 @@ class ConvLSTMCell(nn.Module):
 
     def set_precision(self, precision):
         if precision not in _DTYPES:
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
         self.precision = precision
         return self
 

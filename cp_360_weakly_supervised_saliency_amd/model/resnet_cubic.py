@@ -18,11 +18,11 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .._lib import PRECISIONS as _DTYPES
 from .cube_pad import CubePad
 
 __all__ = ['ResNet', 'Bottleneck', 'resnet50']
 
-_DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
 
 
 def _fold_bn(bn):
@@ -127,7 +127,7 @@ class ResNet(nn.Module):
 
     def set_precision(self, precision):
         if precision not in _DTYPES:
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
         self.precision = precision
         for m in self.modules():
             if isinstance(m, Bottleneck):

@@ -16,7 +16,7 @@ ConvLSTM work seq_len times and is available through ``ClipRunner`` directly).
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from .model.resnet_cubic import resnet50
 from .model.clstm import ConvLSTMCell
 from .static_model.class_activation_model import cam_device
@@ -31,7 +31,7 @@ class SaliencyEngine:
                  input_size=1000, hidden_size=1000, frame_chunk=None):
         self.device = torch.device(device)
         self.precision = precision
-        self.dtype = torch.bfloat16 if precision == 'bf16' else torch.float32
+        self.dtype = _lib.precision_dtype(precision)
         self.B, self.T = int(clips), int(frames)
         self.H, self.W = equi_hw
         self.cube_dim = int(cube_dim)

@@ -9,7 +9,7 @@ results the caller asked for cross PCIe.
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
 
 def cam_device(input_cubemap_nhwc4, model, out=None):
@@ -50,7 +50,7 @@ def CAM(input_cubemap, input_equi, model, feature_layer_name, weight_layer_name,
     dev = next(model.parameters()).device
     if dev.type != 'cuda':
         raise RuntimeError("CAM runs on the GPU only (HIP kernels); move the model with .cuda()")
-    dt = torch.bfloat16 if model.precision == 'bf16' else torch.float32
+    dt = _lib.precision_dtype(model.precision)
     with torch.no_grad():
         img = torch.as_tensor(np.ascontiguousarray(input_cubemap, dtype=np.float32)).to(dev)   # H2D, [6N,H,W,3]
         x4 = ops.cubepad_nhwc(img, 0, c_out=4)                       # NHWC3 -> NHWC4 (pad 0 = channel pad only)

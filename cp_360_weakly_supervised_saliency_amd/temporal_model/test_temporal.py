@@ -5,7 +5,7 @@ the GT metrics of the reference's ``test()`` / ``main()`` are outside the hot pa
 """
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
 
 class ClipRunner:
@@ -15,7 +15,7 @@ class ClipRunner:
     def __init__(self, cell, c2e, B, T, w=7):
         self.cell, self.c2e, self.B, self.T, self.w = cell, c2e, int(B), int(T), int(w)
         dev = next(cell.parameters()).device
-        dt = torch.bfloat16 if cell.precision == 'bf16' else torch.float32
+        dt = _lib.precision_dtype(cell.precision)
         cin, ch = cell.input_size, cell.hidden_size
         n6 = 6 * self.B
         self.P = 6 * w * w

@@ -45,6 +45,7 @@ typedef enum {
 typedef enum {
     CP360_F32 = 0,
     CP360_BF16 = 1,
+    CP360_F16 = 2,
     CP360_U8 = 3
 } cp360_dtype;
 
@@ -125,9 +126,10 @@ int cp360_cube2equi(const float* x, const int8_t* face_map, const float* coord,
  * is fused into the tile loader (pad_mode 1) instead of being materialised.
  */
 typedef struct {
-    int dtype;        /* CP360_F32 (mfma_f32_16x16x4_f32, exact f32) or CP360_BF16
-                         (mfma_f32_16x16x32_bf16, f32 accumulate) - activations,
-                         packed weights and outputs all have this type            */
+    int dtype;        /* CP360_F32 (mfma_f32_16x16x4_f32, exact f32), CP360_BF16
+                         (mfma_f32_16x16x32_bf16) or CP360_F16 (mfma_f32_16x16x32_f16),
+                         f32 accumulate - activations, packed weights and outputs
+                         all have this type                                       */
     int n_img;        /* images (6 * frames)                                      */
     int h_in, w_in;   /* spatial size of the (unpadded) input tensor              */
     int c_in;         /* K elements taken per tap (normally = channels)           */

@@ -182,11 +182,16 @@ CONV_CASES = [
 ]
 
 
+_TDT = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}
+# one output rounding: 2^-8 relative for bf16, 2^-11 for fp16 (f32 accumulate in both)
+_TOL = {'fp32': 2e-5, 'bf16': 1.2e-2, 'fp16': 1.5e-3}
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 def test_conv_matches_torch_cpu(case, prec):
     n_img, cin, cout, n, k, stride, pad, relu, use_res, splits = case
-    dt = torch.float32 if prec == 'fp32' else torch.bfloat16
+    dt = _TDT[prec]
     seed = 9000 + cin + cout
     x = hashrng.normal(seed, (n_img, cin, n, n))
     w = hashrng.normal(seed + 1, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
@@ -194,10 +199,10 @@ def test_conv_matches_torch_cpu(case, prec):
     bias = hashrng.normal(seed + 3, (cout,), 0, 0.1)
     ho = (n + 2 * pad - k) // stride + 1
     res = hashrng.normal(seed + 4, (n_img, cout, ho, ho)) if use_res else None
-    if prec == 'bf16':     # the oracle sees the same rounded operands; accumulation stays f32
-        rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+    if prec != 'fp32':     # the oracle sees the same rounded operands; accumulation stays f32
+        rb = lambda a: torch.from_numpy(a).to(dt).float().numpy()
         x_ref, res_ref = rb(x), (None if res is None else rb(res))
-        w_ref = (torch.from_numpy(w) * torch.from_numpy(scale)[:, None, None, None]).to(torch.bfloat16).float().numpy()
+        w_ref = (torch.from_numpy(w) * torch.from_numpy(scale)[:, None, None, None]).to(dt).float().numpy()
         want = _conv_ref(x_ref, w_ref, None, bias, stride, pad, relu, res_ref)
     else:
         want = _conv_ref(x, w, scale, bias, stride, pad, relu, res)
@@ -206,33 +211,32 @@ def test_conv_matches_torch_cpu(case, prec):
     rt = None if res is None else ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
     got = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits), out_dtype=torch.float32).cpu().numpy()
     assert got.shape == want.shape
-    tol = 2e-5 if prec == 'fp32' else 1.2e-2     # bf16: one output rounding (2^-8 relative)
-    assert rel_err(got, want) <= tol, rel_err(got, want)
+    assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 def test_stem_conv_and_maxpool(prec):
-    dt = torch.float32 if prec == 'fp32' else torch.bfloat16
+    dt = _TDT[prec]
     x = hashrng.normal(9100, (6, 3, 32, 32))
     w = hashrng.normal(9101, (64, 3, 7, 7), 0, (2.0 / (49 * 64)) ** 0.5)
     scale = hashrng.uniform(9102, (64,), 0.5, 1.5)
     bias = hashrng.normal(9103, (64,), 0, 0.1)
-    if prec == 'bf16':
-        rb = lambda a: torch.from_numpy(a).to(torch.bfloat16).float().numpy()
-        w_ref = (torch.from_numpy(w) * torch.from_numpy(scale)[:, None, None, None]).to(torch.bfloat16).float().numpy()
+    if prec != 'fp32':
+        rb = lambda a: torch.from_numpy(a).to(dt).float().numpy()
+        w_ref = (torch.from_numpy(w) * torch.from_numpy(scale)[:, None, None, None]).to(dt).float().numpy()
         stem_ref = _conv_ref(rb(x), w_ref, None, bias, 2, 3, True)
     else:
         stem_ref = _conv_ref(x, w, scale, bias, 2, 3, True)
     conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 2, 0, True, dt, DEV, stem=True)
     x3 = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV))                   # [6,32,32,3] f32
     x4 = ops.cubepad_nhwc(x3, 0, c_out=4)
-    if prec == 'bf16':
+    if prec != 'fp32':
         x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)
     xp = ops.cubepad_nhwc(x4, 3)
     y = conv(xp)
     got = ops.nhwc_to_nchw(y, out_dtype=torch.float32).cpu().numpy()
     assert got.shape == stem_ref.shape == (6, 64, 16, 16)
-    assert rel_err(got, stem_ref) <= (2e-5 if prec == 'fp32' else 1.2e-2)
+    assert rel_err(got, stem_ref) <= _TOL[prec]
     pooled = ops.nhwc_to_nchw(ops.cubepad_maxpool3s2(y), out_dtype=torch.float32).cpu().numpy()
     want_pool = Fn.max_pool2d(o_resnet.cubepad_t(torch.from_numpy(got), 1), 3, 2, 0).numpy()
     assert np.array_equal(pooled, want_pool)     # max of identical values: exact
@@ -426,6 +430,15 @@ def test_pipeline_bf16_end_to_end(e2e_small):
         assert np.max(err) <= 5e-2, np.max(err)
 
 
+def test_pipeline_fp16_end_to_end(e2e_small):
+    s = e2e_small
+    eng = SaliencyEngine(s['rs'], s['cs'], (s['H'], s['W']), s['cd'], clips=s['B'], frames=s['T'], precision='fp16')
+    sal = eng(torch.from_numpy(s['clips']).to(DEV)).cpu().numpy()
+    for b in range(s['B']):
+        err = np.abs(sal[b] - s['refs'][b][0])
+        assert np.max(err) <= 1e-2, np.max(err)      # 8x finer mantissa than bf16 (5e-2 bound above)
+
+
 def test_pipeline_full_size_one_frame_fp32():
     """Config C1/C2 shape: one 960x1920 frame -> 6x224^2 -> CAM, against the oracle."""
     H, W, cd = 960, 1920, 224
@@ -460,9 +473,10 @@ def test_sliding_window_mode_equals_per_window(full_cell_state):
     assert np.max(np.abs(sal[2] - o_clstm.window_saliency(seq[2:2 + T], sd))) <= 1e-3
 
 
-def test_pipeline_c5_shape_fp32():
+def test_pipeline_c5_shape_fp32_and_fp16():
     """BASELINE config C5 geometry: 2048x4096 equirectangular, 6x512^2 cube faces, layer4 / ConvLSTM
-    at 16x16, saliency 32x64 - two frames, fp32, against the oracle."""
+    at 16x16, saliency 32x64 - two frames against the oracle: fp32 within the 1e-3 north-star bound,
+    fp16 (C5's MFMA precision) by the AUC-Judd / CC gate of SURVEY 8(d)."""
     H, W, cd, T = 2048, 4096, 512, 2
     rs = synth.resnet50_state(seed=1)
     cs = synth.clstm_state(seed=2)
@@ -476,3 +490,13 @@ def test_pipeline_c5_shape_fp32():
     mn, mx = want_cam.min(), want_cam.max()
     assert np.max(np.abs((cam - mn) / (mx - mn) - (want_cam - mn) / (mx - mn))) <= 1e-3
     assert np.max(np.abs(sal - ref)) <= 1e-3
+    del eng
+    from oracle import o_metrics
+    eng16 = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision='fp16')
+    sal16 = eng16(torch.from_numpy(clip[None]).to(DEV)).cpu().numpy()[0]
+    fix = synth.fixation_map(150, H // 2, W // 2)
+    auc_ref = o_metrics.auc_judd(ref, fix, rng=np.random.RandomState(0))
+    auc16 = o_metrics.auc_judd(sal16, fix, rng=np.random.RandomState(0))
+    cc_ref, cc16 = o_metrics.corr_coeff(ref, fix), o_metrics.corr_coeff(sal16, fix)
+    print('C5 fp16: max|d| %.3e dAUC %.3e dCC %.3e' % (np.max(np.abs(sal16 - ref)), auc16 - auc_ref, cc16 - cc_ref))
+    assert abs(auc16 - auc_ref) <= 1e-3 and abs(cc16 - cc_ref) <= 1e-3

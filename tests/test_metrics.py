@@ -57,7 +57,7 @@ def test_bf16_auc_cc_gate_full_size(T):
 
     auc_ref, cc_ref = metrics(ref)
     out = {}
-    for prec in ('fp32', 'bf16'):
+    for prec in ('fp32', 'bf16', 'fp16'):
         eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision=prec)
         sal = eng(frames).cpu().numpy()[0]
         auc, cc = metrics(sal)
@@ -69,3 +69,4 @@ def test_bf16_auc_cc_gate_full_size(T):
     assert out['fp32'][0] <= 1e-3
     assert abs(out['fp32'][1]) <= 1e-3 and abs(out['fp32'][2]) <= 1e-3
     assert abs(out['bf16'][1]) <= 1e-3 and abs(out['bf16'][2]) <= 1e-3, out
+    assert abs(out['fp16'][1]) <= 1e-3 and abs(out['fp16'][2]) <= 1e-3, out
