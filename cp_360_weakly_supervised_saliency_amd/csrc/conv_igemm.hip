@@ -128,7 +128,8 @@ __device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
 // not fit the kernel's LDS are processed in two channel halves.
 template <typename T, int BN, int BM, int MJ, int NT, int LDS_BYTES>
 __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds, f32x4 (&acc)[4][MJ], int n0, int m0,
-                                             int wn, int wm, int lane, int tid) {
+                                             int wch0 /* wave's first tile channel */,
+                                             int wrow0 /* wave's first tile row (pixel) */, int lane, int tid) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int NH = (BM * (BN * (int)sizeof(T) + 16) <= LDS_BYTES) ? 1 : 2;   // channel halves
     constexpr int HC = BN / NH;                            // channels per half
@@ -154,7 +155,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int cn = wn * 64 + i * 16;                   // tile channel of this MFMA row block
+            const int cn = wch0 + i * 16;                      // tile channel of this MFMA row block
             if (cn / HC != h) continue;                        // wave-uniform
             const int ncol = cn + nl - h * HC;                 // channel inside this half
             const int n = nh0 + ncol;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
             }
 #pragma unroll
             for (int j = 0; j < MJ; ++j) {
-                const int row = wm * (16 * MJ) + j * 16 + ml;
+                const int row = wrow0 + j * 16 + ml;
                 T* slot = reinterpret_cast<T*>(lds + row * S) + ncol;
                 float v[4] = {acc[i][j][0] + bb[0], acc[i][j][1] + bb[1], acc[i][j][2] + bb[2], acc[i][j][3] + bb[3]};
                 if (res) {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     // ---- epilogue: through LDS (full-line accesses) unless it is a split-K slab or misaligned
     if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
         (p.ld_res % EPC == 0)) {
-        epilogue_lds<T, BN, BM, 4, 256, 2 * STAGE>(p, lds, acc, n0, m0, wn, wm, lane, tid);
+        epilogue_lds<T, BN, BM, 4, 256, 2 * STAGE>(p, lds, acc, n0, m0, wn * 64, wm * 64, lane, tid);
         return;
     }
     // ---- epilogue: lane holds channels n..n+3 of pixel m for every (i, j) sub-tile
@@ -595,8 +596,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     const bool lds_epi = !p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
                          (p.ld_res % EPC == 0);
     if (lds_epi) {
-        epilogue_lds<T, BN, BM, MJ, 512, (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES)>(p, lds, acc, n0, m0, wn, wm,
-                                                                                             lane, tid);
+        epilogue_lds<T, BN, BM, MJ, 512, (PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES)>(
+            p, lds, acc, n0, m0, wn * 64, wm * (16 * MJ), lane, tid);
         return;
     }
 #pragma unroll
@@ -630,55 +631,64 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     }
 }
 
-// ------------------------------------------------------------------ 256x256 tile, 4-stage ring
-// Same tile and wave layout as conv_igemm_dma_kernel<T, 8>, but the K step is HALF a line
-// (64 bytes per tile row = one MFMA k-block) and the LDS holds a ring of FOUR 32 KiB stages:
+// ------------------------------------------------------------------ 256 x {256, 304} tile, 4-stage ring
+// Same 8-wave / 256-channel tile as conv_igemm_dma_kernel<T, 8>, but the K step is HALF a line
+// (64 bytes per tile row = one MFMA k-block) and the LDS holds a ring of FOUR stages:
 // the DMA of sub-step s+3 is issued at the start of sub-step s, so a load has three MFMA
 // phases (1.5 of the 2-stage kernel's steps) to arrive - the 2-stage kernel spent ~30 % of its
 // wave cycles in s_waitcnt/barrier (SQ_WAIT_ANY, profiles/).  A DMA wave-instruction now
 // covers 16 rows x 64 B; LDS rows are 64 B = 4 chunks, chunk c of row r stored at chunk
 // c ^ ((-(r >> 2)) & 3), which keeps every 16-lane ds_read_b128 group on 16 distinct 16-byte
 // slots of the 256-byte bank row (4 rows per bank row).
+//
+// Pixel-tile width BM:
+//   256: waves = 4 channel quarters x 2 pixel halves, 4 x 8 MFMA tiles each.
+//   304: for the ConvLSTM at 7x7 faces, where a clip is 6*49 = 294 pixels: 19 sixteen-pixel
+//        blocks per tile, so B clips are exactly B tiles (M = 1176 pads to 1216 instead of 1280,
+//        and 16 channel tiles x 4 pixel tiles x 4 K-splits = 256 workgroups = one per CU).
+//        Waves 0-3 (channel quarter = wave) take pixel blocks 0-9, waves 4-7 blocks 10-18: the
+//        two waves that share a SIMD (w and w+4) carry 10 + 9 blocks, so every SIMD's matrix
+//        pipe has the same work.  The 48 extra activation rows are one more DMA instruction
+//        for waves 0-2 (their vmcnt budget is counted separately).
 __device__ __forceinline__ int lds_swz64(int row, int chunk) {
     return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
 }
 
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) {
-    constexpr int BN = 256, BM = 256, MJ = 8, NSTAGE = 4;
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM> struct RingGeom {
+    static constexpr int BN = 256, NSTAGE = 4;
+    static constexpr int A_PASSES = BN / 128;                    // 128 tile rows per 512-thread pass
+    static constexpr int B_FULL = BM / 128;                      // full activation passes
+    static constexpr int B_REM = BM % 128;                       // rows of the partial pass (0 or 48)
+    static constexpr int B_PASSES = B_FULL + (B_REM ? 1 : 0);
+    static constexpr int XWAVES = B_REM / 16;                    // waves that issue the partial pass
+    static constexpr int DMA_BASE = A_PASSES + B_FULL;           // DMA instructions per sub-step (every wave)
+    static constexpr int STAGE = (BN + BM) * 64;
+    template <typename T> static constexpr int epi_bytes() {
+        return BM * (BN / (sizeof(T) == 4 ? 2 : 1) * (int)sizeof(T) + 16);
+    }
+    template <typename T> static constexpr int lds_bytes() {
+        return NSTAGE * STAGE > epi_bytes<T>() ? NSTAGE * STAGE : epi_bytes<T>();
+    }
+};
+
+// K loop + epilogue of one wave: channels [wch0, wch0+64) x MJ pixel blocks from tile row wrow0.
+// JH = pixel blocks whose activation fragments are held at once (MJ, or half of it to stay
+// inside 256 VGPRs when MJ = 10).
+template <typename T, int BM, int MJ, int JH>
+__device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, const int n0, const int m0, const int split,
+                                          const int wave, const int lane, const int tid, const int wch0,
+                                          const int wrow0) {
+    typedef RingGeom<BM> G;
+    constexpr int BN = G::BN, STAGE = G::STAGE, A_PASSES = G::A_PASSES, B_PASSES = G::B_PASSES;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BKS = 4 * EPC;                               // K elements per sub-step (64 bytes)
-    constexpr int A_PASSES = BN / 128, B_PASSES = BM / 128;     // 128 tile rows per 512-thread pass
-    constexpr int DMA_PER_STEP = A_PASSES + B_PASSES;           // 4
-    constexpr int STAGE = (BN + BM) * 64;                       // 32 KiB
-    constexpr int EPI_BYTES = BM * (BN / (sizeof(T) == 4 ? 2 : 1) * (int)sizeof(T) + 16);
-    constexpr int PIPE_BYTES = NSTAGE * STAGE;
-    constexpr int LDS_BYTES = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    constexpr int D0 = G::DMA_BASE, D1 = G::DMA_BASE + 1;
+    const bool xw = G::XWAVES > 0 && wave < G::XWAVES;         // wave-uniform: this wave issues the partial pass
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wm = wave & 1;
-    int n0, m0, split;
-    {
-        const int nwg = p.nt * p.mt * p.splits;
-        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        int nt_i, mt_i;
-        if (p.m_fast) {
-            mt_i = w % p.mt;
-            const int rest = w / p.mt;
-            nt_i = rest % p.nt;
-            split = rest / p.nt;
-        } else {
-            nt_i = w % p.nt;
-            const int rest = w / p.nt;
-            mt_i = rest % p.mt;
-            split = rest / p.mt;
-        }
-        n0 = nt_i * BN;
-        m0 = mt_i * BM;
-    }
     // DMA role: 16 rows x 4 chunks per wave-instruction; lane l lands in row l>>2, physical
     // chunk l&3 and therefore fetches logical chunk (l&3) ^ f(row), f = (-(row>>2)) & 3
     const int drow = 16 * wave + (lane >> 2);                                  // row inside a 128-row pass
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
         for (int pb = 0; pb < B_PASSES; ++pb) {
             const int m = m0 + drow + 128 * pb;
             int off = -1;
-            if (m < p.M) {
+            if (m < p.M && (pb < G::B_FULL || xw)) {
                 const int img = m / p.hw_out, rem = m - img * p.hw_out;
                 const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
                 const int py = oy * p.sy + ky, px = ox * p.sx + kx;
@@ -723,7 +733,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     const unsigned lds_base = (unsigned)(size_t)lds;
     const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;          // this wave's 1 KiB inside a pass
 
-    // DMA of one pass (q = 0,1: weight rows, 2,3: activation rows) of the CURRENT (tap, c0)
+    // DMA of one pass (q < A_PASSES: weight rows, else activation rows) of the CURRENT (tap, c0)
     auto issue_one = [&](int q, unsigned sbase) __attribute__((always_inline)) {
         if (q < A_PASSES) {
             glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);
@@ -738,7 +748,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     auto issue = [&](int stage) __attribute__((always_inline)) {
         const unsigned sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * STAGE);
 #pragma unroll
-        for (int q = 0; q < DMA_PER_STEP; ++q) issue_one(q, sbase);
+        for (int q = 0; q < D0; ++q) issue_one(q, sbase);
+        if (G::XWAVES > 0 && xw) issue_one(D0, sbase);
     };
     auto advance = [&]() __attribute__((always_inline)) {
         c0 += BKS;
@@ -762,41 +773,50 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
         if (nloc > 1) { advance(); issue(1); }
         if (nloc > 2) { advance(); issue(2); }
         int stage = 0;
-        // One sub-step.  REFILL: the four DMA instructions that refill the stage freed by the
-        // barrier are spread between the four 8-MFMA groups (their address arithmetic and the
+        // One sub-step.  REFILL: the DMA instructions that refill the stage freed by the
+        // barrier are spread between the 4 MFMA groups (their address arithmetic and the
         // SALU/M0 traffic then issue in the shadow of MFMAs instead of in front of them); the
         // first one goes out under the latency of the fragment reads.
 #define CP360_RING_STEP(REFILL)                                                                            \
         {                                                                                                  \
             const unsigned char* As = lds + stage * STAGE;                                                 \
             const unsigned char* Bs = As + BN * 64;                                                        \
-            u32x4 a[4], b[MJ];                                                                             \
+            u32x4 a[4], b[JH];                                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
-                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wn * 64 + i * 16 + lrow, lchunk));   \
-            _Pragma("unroll") for (int j = 0; j < MJ; ++j)                                                 \
-                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wm * (16 * MJ) + j * 16 + lrow, lchunk)); \
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \
+            _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                 \
+                b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + j * 16 + lrow, lchunk));     \
             unsigned sbase = 0;                                                                            \
             if (REFILL) {                                                                                  \
                 advance();                                                                                 \
                 sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)((stage + 3) & 3) * STAGE);    \
             }                                                                                              \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-                if (REFILL) issue_one(i, sbase);                                                           \
-                _Pragma("unroll") for (int j = 0; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);        \
+                if (REFILL && i < D0) issue_one(i, sbase);                                                 \
+                _Pragma("unroll") for (int j = 0; j < JH; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);        \
+            }                                                                                              \
+            if (JH < MJ) {                                                                                 \
+                _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                            \
+                    b[j - JH] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + j * 16 + lrow, lchunk)); \
+                if (REFILL && G::XWAVES > 0 && xw) issue_one(D0, sbase);                                   \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+                    _Pragma("unroll") for (int j = JH; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j - JH]); \
+            } else if (REFILL && G::XWAVES > 0 && xw) {                                                    \
+                issue_one(D0, sbase);                                                                      \
             }                                                                                              \
             stage = (stage + 1) & 3;                                                                       \
         }
         int it = 0;
         for (; it + 3 < nloc; ++it) {               // steady state: two younger DMA groups in flight
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_STEP) : "memory");
+            if (xw) wait_vmcnt<2 * D1>(); else wait_vmcnt<2 * D0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             CP360_RING_STEP(true)
         }
         for (; it < nloc; ++it) {                   // drain: no refill
-            if (it + 2 < nloc)      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DMA_PER_STEP) : "memory");
-            else if (it + 1 < nloc) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_STEP) : "memory");
-            else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (it + 2 < nloc)      { if (xw) wait_vmcnt<2 * D1>(); else wait_vmcnt<2 * D0>(); }
+            else if (it + 1 < nloc) { if (xw) wait_vmcnt<D1>(); else wait_vmcnt<D0>(); }
+            else                    wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             CP360_RING_STEP(false)
@@ -807,16 +827,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     const int nl = (lane >> 4) * 4, ml = lane & 15;
     if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
         (p.ld_res % EPC == 0)) {
-        epilogue_lds<T, BN, BM, MJ, 512, LDS_BYTES>(p, lds, acc, n0, m0, wn, wm, lane, tid);
+        epilogue_lds<T, BN, BM, MJ, 512, G::template lds_bytes<T>()>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid);
         return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + nl;
+        const int n = n0 + wch0 + i * 16 + nl;
         if (n >= p.c_out) continue;
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
-            const int m = m0 + wm * (16 * MJ) + j * 16 + ml;
+            const int m = m0 + wrow0 + j * 16 + ml;
             if (m >= p.M) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
@@ -838,6 +858,42 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
                 store4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ld_out + p.out_coff + n, v);
             }
         }
+    }
+}
+
+template <typename T, int BM>
+__global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) {
+    typedef RingGeom<BM> G;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::template lds_bytes<T>()];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int n0, m0, split;
+    {
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int nt_i, mt_i;
+        if (p.m_fast) {
+            mt_i = w % p.mt;
+            const int rest = w / p.mt;
+            nt_i = rest % p.nt;
+            split = rest / p.nt;
+        } else {
+            nt_i = w % p.nt;
+            const int rest = w / p.nt;
+            mt_i = rest % p.mt;
+            split = rest / p.mt;
+        }
+        n0 = nt_i * G::BN;
+        m0 = mt_i * BM;
+    }
+    if constexpr (BM == 256) {
+        ring_body<T, 256, 8, 8>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 128);
+    } else {
+        static_assert(BM == 304, "pixel tile is 256 or 304");
+        if (wave < 4) ring_body<T, 304, 10, 5>(p, lds, n0, m0, split, wave, lane, tid, wave * 64, 0);
+        else          ring_body<T, 304, 9, 5>(p, lds, n0, m0, split, wave, lane, tid, (wave - 4) * 64, 160);
     }
 }
 
@@ -962,6 +1018,7 @@ static int check_desc(const cp360_conv_desc* d) {
         d->sx <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_out <= 0 || d->splits < 1 || d->pix_stride <= 0)
         return CP360_ERR_BAD_SHAPE;
     const int epc = 16 / elem_bytes(d->dtype);
+    if (d->tile_px != 0 && d->tile_px != 128 && d->tile_px != 256 && d->tile_px != 304) return CP360_ERR_BAD_SHAPE;
     if (d->c_in % epc != 0 || d->c_out % 4 != 0 || d->ld_out % 4 != 0 || d->out_coff % 4 != 0 || d->ld_res % 4 != 0)
         return CP360_ERR_ALIGN;
     if (d->ld_out < d->c_out + d->out_coff) return CP360_ERR_BAD_SHAPE;
@@ -1027,19 +1084,23 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
 static ConvPlan plan_of(const cp360_conv_desc* d) {
     if (d->c_out <= 64) return plan_candidate(d, 64, 256, 512, 1.5);
     if (d->c_out < 256) return plan_candidate(d, 128, 128, 512, 1.5);
-    const ConvPlan a = plan_candidate(d, 256, 256, 256, 2.2);
+    ConvPlan best = plan_candidate(d, 256, 256, 256, 2.2);
     const ConvPlan b = plan_candidate(d, 256, 128, 256, 1.25);
-    return a.cost <= b.cost ? a : b;
+    if (b.cost < best.cost) best = b;
+    static const int no304 = []() {
+        const char* e = getenv("CP360_NO304");             // A/B switch for tools/bench_conv.py
+        return e ? atoi(e) : 0;
+    }();
+    const ConvPlan c = plan_candidate(d, 256, 304, 256, 2.2 * 304.0 / 256.0);   // 19 pixel blocks: 7x7 cube faces
+    if (!no304 && c.cost < best.cost) best = c;
+    return best;
 }
 
 // Tile geometry for a given (caller-chosen) split count: same candidates, splits fixed.
 static void tile_of(const cp360_conv_desc* d, int* bn, int* bm, int* slots) {
-    ConvPlan pl = plan_of(d);
-    if (d->c_out >= 256 && d->splits != pl.splits) {
-        // the caller overrode the split count: keep the tile the model prefers at ITS best split
-    }
+    ConvPlan pl = plan_of(d);      // a caller-chosen split count keeps the tile the model prefers at ITS best split
     *bn = pl.bn;
-    *bm = pl.bm;
+    *bm = (d->c_out >= 256 && d->tile_px) ? d->tile_px : pl.bm;
     *slots = pl.slots;
 }
 
@@ -1120,7 +1181,7 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
         // pixel count pads badly (small-M launches) - then 256x128
         int bn_, bm_, slots_;
         tile_of(d, &bn_, &bm_, &slots_);
-        const bool big = bm_ == 256;
+        const bool big = bm_ >= 256;
         const int bm = bm_;
         k.nt = (k.c_out + 255) / 256;
         k.mt = (k.M + bm - 1) / bm;
@@ -1132,7 +1193,8 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
         }();
 #define CP360_WIDE(TT)                                                                                     \
         {                                                                                                      \
-            if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT>), grid, dim3(512), 0, st, k);  \
+            if (bm == 304) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 304>), grid, dim3(512), 0, st, k);   \
+            else if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 256>), grid, dim3(512), 0, st, k); \
             else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 8>), grid, dim3(512), 0, st, k);       \
             else          hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 4>), grid, dim3(512), 0, st, k);       \
         }

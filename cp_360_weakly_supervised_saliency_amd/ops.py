@@ -192,7 +192,7 @@ class Conv:
         return (h_in + p2 - self.kh) // self.stride + 1, \
                ((w_in + p2 - self.kw_w) // self.stride + 1 if self.stem else (w_in + p2 - self.kw) // self.stride + 1)
 
-    def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None):
+    def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None, tile_px=0):
         d = ConvDesc()
         d.dtype = dtype_code(self.dtype)
         d.n_img, d.h_in, d.w_in = n_img, h_in, w_in
@@ -205,13 +205,15 @@ class Conv:
         d.out_coff, d.ld_res = out_coff, ld_res
         d.relu = int(self.relu if relu is None else relu)
         d.splits = splits
+        d.tile_px = tile_px
         return d
 
     def nsteps(self):
         bk = 32 if self.dtype == torch.float32 else 64
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
 
-    def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None):
+    def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None,
+                 tile_px=0):
         """x [n_img, h, w, c] NHWC (for the stem: the materialised CubePad(3) output
         [n_img, h+6, w+6, 4]).  Returns [n_img, h_out, w_out, c_out] in self.dtype, or
         with raw_f32=True the (partial [splits, M, c_out] f32, splits) pair whose
@@ -235,7 +237,7 @@ class Conv:
             if splits is None:
                 splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1)))
                 self._splits_cache[key] = splits
-        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res)
+        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res, tile_px=tile_px)
         def forward(*a):
             if LAUNCH_TIMER is None:
                 return L.cp360_conv_forward(*a)

@@ -146,6 +146,8 @@ typedef struct {
     int ld_res;       /* residual pixel stride (0 when residual == NULL)          */
     int relu;
     int splits;       /* split-K factor (>= 1); > 1 needs `partial`               */
+    int tile_px;      /* 0: the library's launch planner picks the pixel tile; 128 /
+                         256 / 304 force it for c_out >= 256 (tuning, tests)      */
 } cp360_conv_desc;
 
 /* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */

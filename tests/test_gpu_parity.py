@@ -214,6 +214,29 @@ def test_conv_matches_torch_cpu(case, prec):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('tile_px', [128, 256, 304])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('splits', [1, 3])
+def test_wide_conv_forced_pixel_tiles(tile_px, prec, splits):
+    """c_out >= 256 kernels with the pixel tile forced (cp360_conv_desc.tile_px): 256x128 LDS-DMA,
+    256x256 ring and the 256x304 ring (19 pixel blocks: waves 0-3 carry 10, waves 4-7 carry 9, three
+    waves issue the partial DMA pass).  M = 2*294 = 588 pixels: a full 304 tile + a ragged one; c_out =
+    264 gives a ragged channel tile; residual + ReLU exercise the LDS epilogue, splits = 3 the slabs."""
+    dt = _TDT[prec]
+    n_img, cin, cout, n, k = 12, 96, 264, 7, 3
+    x = hashrng.normal(9300, (n_img, cin, n, n))
+    w = hashrng.normal(9301, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
+    bias = hashrng.normal(9303, (cout,), 0, 0.1)
+    res = hashrng.normal(9304, (n_img, cout, n, n))
+    rb = (lambda a: torch.from_numpy(a).to(dt).float().numpy()) if prec != 'fp32' else (lambda a: a)
+    want = _conv_ref(rb(x), rb(w), None, bias, 1, 1, True, rb(res))
+    conv = ops.Conv(torch.from_numpy(w), None, torch.from_numpy(bias), 1, 1, True, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    rt = ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
+    got = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits, tile_px=tile_px), out_dtype=torch.float32).cpu().numpy()
+    assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 def test_stem_conv_and_maxpool(prec):
     dt = _TDT[prec]

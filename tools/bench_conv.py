@@ -16,8 +16,9 @@ ap.add_argument('--frames', type=int, default=64)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--only', default='')
 ap.add_argument('--splits', type=int, default=0)
+ap.add_argument('--tile-px', type=int, default=0)
 args = ap.parse_args()
-dt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.precision]
 dev = 'cuda'
 B, F = args.clips, args.frames
 # (name, n_img, cin, cout, n, k, stride, pad)
@@ -42,6 +43,8 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     conv = ops.Conv(w, None, torch.zeros(cout), s, pad, True, dt, dev)
     x = torch.randn(n_img, n, n, cin, device=dev).to(dt)
     kw = {'splits': args.splits} if args.splits else {}
+    if args.tile_px:
+        kw['tile_px'] = args.tile_px
     y = conv(x, **kw)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
