@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libcp360.so')
+# CP360_LIB: an alternative build of the SAME library (kernel experiments, tools/exp_build.sh)
+LIB_PATH = os.environ.get('CP360_LIB') or os.path.join(_HERE, 'csrc', 'libcp360.so')
 
 F32, BF16, F16, U8 = 0, 1, 2, 3
 

@@ -136,6 +136,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
     constexpr int CPR = HC / EPC;                          // 16-byte chunks per tile row
     constexpr int S = HC * (int)sizeof(T) + 16;            // LDS row stride (bytes), 16-byte aligned
     static_assert(BM * S <= LDS_BYTES, "epilogue tile does not fit the LDS of this kernel");
+    constexpr int UB = MJ > 8 ? 4 : 8;                     // 16-byte accesses in flight per thread (register budget)
     const int nl = (lane >> 4) * 4, ml = lane & 15;
     const T* res = reinterpret_cast<const T*>(p.res);
     T* outp = reinterpret_cast<T*>(p.out);
@@ -144,12 +145,27 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
         __syncthreads();                                   // previous users of the LDS are done
         const int nh0 = n0 + h * HC;
         if (res) {
-            for (int q = tid; q < BM * CPR; q += NT) {
-                const int row = q / CPR, c = q - row * CPR;
-                const int m = m0 + row, n = nh0 + c * EPC;
-                if (m < p.M && n < p.c_out)
-                    *reinterpret_cast<u32x4*>(lds + row * S + c * 16) =
-                        *reinterpret_cast<const u32x4*>(res + (size_t)m * p.ld_res + n);
+            // batches of UB independent 16-byte loads in flight per thread before the first LDS store:
+            // one load per iteration serialised a full HBM latency per 16 bytes (the 1x1 expansion
+            // convs of ResNet spent most of their time here)
+#pragma unroll 1
+            for (int q0 = tid; q0 < BM * CPR; q0 += NT * UB) {
+                u32x4 r[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int q = q0 + u * NT;
+                    const int row = q / CPR, c = q - row * CPR;
+                    const int m = m0 + row, n = nh0 + c * EPC;
+                    const bool ok = q < BM * CPR && m < p.M && n < p.c_out;
+                    r[u] = *reinterpret_cast<const u32x4*>(ok ? res + (size_t)m * p.ld_res + n
+                                                              : reinterpret_cast<const T*>(g_zero16));
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int q = q0 + u * NT;
+                    const int row = q / CPR, c = q - row * CPR;
+                    if (q < BM * CPR) *reinterpret_cast<u32x4*>(lds + row * S + c * 16) = r[u];
+                }
             }
             __syncthreads();
         }
@@ -182,12 +198,23 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
             }
         }
         __syncthreads();
-        for (int q = tid; q < BM * CPR; q += NT) {
-            const int row = q / CPR, c = q - row * CPR;
-            const int m = m0 + row, n = nh0 + c * EPC;
-            if (m < p.M && n < p.c_out)
-                *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ld_out + p.out_coff + n) =
-                    *reinterpret_cast<const u32x4*>(lds + row * S + c * 16);
+#pragma unroll 1
+        for (int q0 = tid; q0 < BM * CPR; q0 += NT * UB) {
+            u32x4 r[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int q = q0 + u * NT;
+                const int row = q / CPR, c = q - row * CPR;
+                if (q < BM * CPR) r[u] = *reinterpret_cast<const u32x4*>(lds + row * S + c * 16);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int q = q0 + u * NT;
+                const int row = q / CPR, c = q - row * CPR;
+                const int m = m0 + row, n = nh0 + c * EPC;
+                if (q < BM * CPR && m < p.M && n < p.c_out)
+                    *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ld_out + p.out_coff + n) = r[u];
+            }
         }
     }
 }
@@ -676,9 +703,9 @@ template <int BM> struct RingGeom {
 };
 
 // K loop + epilogue of one wave: channels [wch0, wch0+64) x MJ pixel blocks from tile row wrow0.
-// JH = pixel blocks whose activation fragments are held at once (MJ, or half of it to stay
-// inside 256 VGPRs when MJ = 10).
-template <typename T, int BM, int MJ, int JH>
+// JH = pixel blocks of the first half of a sub-step (their activation fragments are held at once;
+// the other MJ - JH reuse the registers).  LAG: this wave runs half a sub-step behind (waves 4-7).
+template <typename T, int BM, int MJ, int JH, bool LAG>
 __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, const int n0, const int m0, const int split,
                                           const int wave, const int lane, const int tid, const int wch0,
                                           const int wrow0) {
@@ -773,15 +800,30 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
         if (nloc > 1) { advance(); issue(1); }
         if (nloc > 2) { advance(); issue(2); }
         int stage = 0;
-        // One sub-step.  REFILL: the DMA instructions that refill the stage freed by the
-        // barrier are spread between the 4 MFMA groups (their address arithmetic and the
-        // SALU/M0 traffic then issue in the shadow of MFMAs instead of in front of them); the
-        // first one goes out under the latency of the fragment reads.
-#define CP360_RING_STEP(REFILL)                                                                            \
+        // A sub-step is two PHASES separated by a second barrier, and the two waves that share a
+        // SIMD (w and w+4) run half a sub-step apart (MI355X_MICROARCH.md, "Two waves per SIMD",
+        // item 9).  HEAD = fragment reads of the sub-step's stage (a[4] + the first JH pixel
+        // blocks), the refill DMA and the first JH*4 MFMAs, column by column: as soon as the four
+        // MFMAs of column j are issued its registers are re-loaded with pixel block JH + j, so the
+        // second half's operands arrive under the first half's MFMAs; TAIL = the remaining MFMAs,
+        // all operands in registers.
+        //   waves 0-3 (LAG = false):  B1  HEAD(s)    B2  TAIL(s)
+        //   waves 4-7 (LAG = true ):  B1  TAIL(s-1)  B2  HEAD(s)
+        // so while one wave of a SIMD waits for its LDS reads the other feeds the matrix pipe from
+        // registers.  Stage s is read between B1(s) and B1(s+1) by both groups and refilled (with
+        // sub-step s+4) after B1(s+1), exactly as without the stagger; a lagging wave drains its
+        // LDS reads (lgkmcnt) before B1 because the tail operands it read last are first used after it.
+        u32x4 a[4], b[JH];
+        if (LAG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < JH; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
+        }
+#define CP360_RING_HEAD(REFILL)                                                                            \
         {                                                                                                  \
             const unsigned char* As = lds + stage * STAGE;                                                 \
             const unsigned char* Bs = As + BN * 64;                                                        \
-            u32x4 a[4], b[JH];                                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
                 a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \
             _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                 \
@@ -791,37 +833,46 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
                 advance();                                                                                 \
                 sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)((stage + 3) & 3) * STAGE);    \
             }                                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-                if (REFILL && i < D0) issue_one(i, sbase);                                                 \
-                _Pragma("unroll") for (int j = 0; j < JH; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);        \
+            _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                               \
+                if (REFILL && j < D0) issue_one(j, sbase);                                                 \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);         \
+                if (JH + j < MJ)   /* column j is done: its registers take pixel block JH + j */           \
+                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + (JH + j) * 16 + lrow, lchunk)); \
             }                                                                                              \
-            if (JH < MJ) {                                                                                 \
-                _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                            \
-                    b[j - JH] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + j * 16 + lrow, lchunk)); \
-                if (REFILL && G::XWAVES > 0 && xw) issue_one(D0, sbase);                                   \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-                    _Pragma("unroll") for (int j = JH; j < MJ; ++j) mma_chunk<T>(acc[i][j], a[i], b[j - JH]); \
-            } else if (REFILL && G::XWAVES > 0 && xw) {                                                    \
-                issue_one(D0, sbase);                                                                      \
-            }                                                                                              \
+            if (REFILL && G::XWAVES > 0 && xw) issue_one(D0, sbase);                                       \
             stage = (stage + 1) & 3;                                                                       \
+        }
+#define CP360_RING_TAIL()                                                                                  \
+        {                                                                                                  \
+            _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                                \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j - JH]);    \
+        }
+#define CP360_RING_STEP(REFILL)                                                                            \
+        {                                                                                                  \
+            if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (!LAG) CP360_RING_HEAD(REFILL) else CP360_RING_TAIL()                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (!LAG) CP360_RING_TAIL() else CP360_RING_HEAD(REFILL)                                       \
         }
         int it = 0;
         for (; it + 3 < nloc; ++it) {               // steady state: two younger DMA groups in flight
             if (xw) wait_vmcnt<2 * D1>(); else wait_vmcnt<2 * D0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
             CP360_RING_STEP(true)
         }
         for (; it < nloc; ++it) {                   // drain: no refill
             if (it + 2 < nloc)      { if (xw) wait_vmcnt<2 * D1>(); else wait_vmcnt<2 * D0>(); }
             else if (it + 1 < nloc) { if (xw) wait_vmcnt<D1>(); else wait_vmcnt<D0>(); }
             else                    wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
             CP360_RING_STEP(false)
         }
+        if (LAG) CP360_RING_TAIL()
 #undef CP360_RING_STEP
+#undef CP360_RING_HEAD
+#undef CP360_RING_TAIL
     }
 
     const int nl = (lane >> 4) * 4, ml = lane & 15;
@@ -889,11 +940,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
         m0 = mt_i * BM;
     }
     if constexpr (BM == 256) {
-        ring_body<T, 256, 8, 8>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 128);
+        if (wave < 4) ring_body<T, 256, 8, 4, false>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 128);
+        else          ring_body<T, 256, 8, 4, true>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 128);
     } else {
         static_assert(BM == 304, "pixel tile is 256 or 304");
-        if (wave < 4) ring_body<T, 304, 10, 5>(p, lds, n0, m0, split, wave, lane, tid, wave * 64, 0);
-        else          ring_body<T, 304, 9, 5>(p, lds, n0, m0, split, wave, lane, tid, (wave - 4) * 64, 160);
+        if (wave < 4) ring_body<T, 304, 10, 5, false>(p, lds, n0, m0, split, wave, lane, tid, wave * 64, 0);
+        else          ring_body<T, 304, 9, 5, true>(p, lds, n0, m0, split, wave, lane, tid, (wave - 4) * 64, 160);
     }
 }
 
@@ -1018,7 +1070,8 @@ static int check_desc(const cp360_conv_desc* d) {
         d->sx <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_out <= 0 || d->splits < 1 || d->pix_stride <= 0)
         return CP360_ERR_BAD_SHAPE;
     const int epc = 16 / elem_bytes(d->dtype);
-    if (d->tile_px != 0 && d->tile_px != 128 && d->tile_px != 256 && d->tile_px != 304) return CP360_ERR_BAD_SHAPE;
+    if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 256 && d->tile_px != 304)
+        return CP360_ERR_BAD_SHAPE;
     if (d->c_in % epc != 0 || d->c_out % 4 != 0 || d->ld_out % 4 != 0 || d->out_coff % 4 != 0 || d->ld_res % 4 != 0)
         return CP360_ERR_ALIGN;
     if (d->ld_out < d->c_out + d->out_coff) return CP360_ERR_BAD_SHAPE;
@@ -1100,8 +1153,17 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
 static void tile_of(const cp360_conv_desc* d, int* bn, int* bm, int* slots) {
     ConvPlan pl = plan_of(d);      // a caller-chosen split count keeps the tile the model prefers at ITS best split
     *bn = pl.bn;
-    *bm = (d->c_out >= 256 && d->tile_px) ? d->tile_px : pl.bm;
+    *bm = pl.bm;
     *slots = pl.slots;
+    if (d->c_out >= 256 && d->tile_px == 64) {       // forced: the 4-wave 128x128 kernel
+        *bn = 128;
+        *bm = 128;
+        *slots = 512;
+    } else if (d->c_out >= 256 && d->tile_px) {
+        *bn = 256;
+        *bm = d->tile_px;
+        *slots = 256;
+    }
 }
 
 extern "C" int cp360_conv_suggest_splits(const cp360_conv_desc* d) {
@@ -1175,12 +1237,12 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     k.k_total = d->kh * d->kw * k.c_pad;
     hipStream_t st = (hipStream_t)stream;
     const bool narrow = d->c_out <= 64;
-    const bool wide = d->c_out >= 256;
+    int bn_ = 0, bm_ = 0, slots_ = 0;
+    if (d->c_out >= 256) tile_of(d, &bn_, &bm_, &slots_);
+    const bool wide = d->c_out >= 256 && bn_ == 256;           // else: the 4-wave 128x128 kernel, two workgroups per CU
     if (wide) {
         // 256x256 tiles carry 1.5x the flops per byte brought into the CU; use them unless the
         // pixel count pads badly (small-M launches) - then 256x128
-        int bn_, bm_, slots_;
-        tile_of(d, &bn_, &bm_, &slots_);
         const bool big = bm_ >= 256;
         const int bm = bm_;
         k.nt = (k.c_out + 255) / 256;

@@ -146,8 +146,10 @@ typedef struct {
     int ld_res;       /* residual pixel stride (0 when residual == NULL)          */
     int relu;
     int splits;       /* split-K factor (>= 1); > 1 needs `partial`               */
-    int tile_px;      /* 0: the library's launch planner picks the pixel tile; 128 /
-                         256 / 304 force it for c_out >= 256 (tuning, tests)      */
+    int tile_px;      /* 0: the library's launch planner picks the tile; for c_out >=
+                         256 (tuning, tests): 128 / 256 / 304 force the pixel tile
+                         of the 8-wave 256-channel kernels, 64 forces the 4-wave
+                         128x128 kernel                                           */
 } cp360_conv_desc;
 
 /* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */

@@ -16,6 +16,7 @@ ap.add_argument('--frames', type=int, default=64)
 ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--only', default='')
 ap.add_argument('--splits', type=int, default=0)
+ap.add_argument('--residual', action='store_true', help='add a residual input (ResNet conv3)')
 ap.add_argument('--tile-px', type=int, default=0)
 args = ap.parse_args()
 dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.precision]
@@ -28,6 +29,7 @@ shapes = [
     ('l1.conv1 1x1', 6 * F, 256, 64, 56, 1, 1, 0),
     ('l1.conv2 3x3', 6 * F, 64, 64, 56, 3, 1, 1),
     ('l1.conv3 1x1', 6 * F, 64, 256, 56, 1, 1, 0),
+    ('l2.conv1 1x1', 6 * F, 512, 128, 28, 1, 1, 0),
     ('l2.conv2 3x3', 6 * F, 128, 128, 28, 3, 1, 1),
     ('l2.conv3 1x1', 6 * F, 128, 512, 28, 1, 1, 0),
     ('l3.conv2 3x3', 6 * F, 256, 256, 14, 3, 1, 1),
@@ -45,6 +47,9 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     kw = {'splits': args.splits} if args.splits else {}
     if args.tile_px:
         kw['tile_px'] = args.tile_px
+    if args.residual:
+        ho_ = (n + 2 * pad - k) // s + 1
+        kw['residual'] = torch.randn(n_img, ho_, ho_, cout, device=dev).to(dt)
     y = conv(x, **kw)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Source patches for tools/exp_build.sh (timing experiments on the ring kernel; see there)."""
+import sys
+
+path, variants = sys.argv[1], sys.argv[2].split('+')
+s = open(path).read()
+
+
+def sub(a, b, count=None):
+    global s
+    assert a in s, a
+    s = s.replace(a, b) if count is None else s.replace(a, b, count)
+
+
+for v in variants:
+    if v == 'base':
+        pass
+    elif v == 'nomma':
+        i = s.index('template <>\n__device__ __forceinline__ void mma_chunk<bf16_raw>')
+        j = s.index('}\n', i) + 2
+        s = s[:i] + ('template <>\n__device__ __forceinline__ void mma_chunk<bf16_raw>(f32x4& acc, const u32x4& a, '
+                     'const u32x4& b) {\n    acc[0] = __uint_as_float(__float_as_uint(acc[0]) ^ a.x ^ b.x);\n}\n') + s[j:]
+    elif v in ('wonly', 'l2only'):
+        sub('const bool ok = e < p.c_in && roff[pb] >= 0;', 'const bool ok = false;')
+    if v in ('aonly', 'l2only'):
+        sub('(size_t)(n0 + drow) * p.k_total + dchunk * EPC;', '(size_t)0 + dchunk * EPC;')
+        sub('const size_t wpass = (size_t)128 * p.k_total;', 'const size_t wpass = 0;')
+    if v in ('wsc1', 'wnt'):     # weight DMA bypasses L1 (sc1) / non-temporal
+        mod = 'sc1' if v == 'wsc1' else 'nt'
+        sub('__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {',
+            '__device__ __forceinline__ void glds16w(const void* gsrc, unsigned lds_dst) {\n    unsigned keep;\n'
+            '    asm volatile("s_mov_b32 %0, m0\\n\\ts_mov_b32 m0, %2\\n\\ts_nop 0\\n\\t'
+            'global_load_lds_dwordx4 %1, off ' + mod + '\\n\\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");\n}\n'
+            '__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {')
+        sub('glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);',
+            'glds16w(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);')
+    if v == 'fullline':
+        sub('const int drow = 16 * wave + (lane >> 2);', 'const int drow = 16 * wave + (lane >> 3);')
+        sub('const int dchunk = (lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3);', 'const int dchunk = lane & 7;')
+        sub('glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);',
+            'glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + (c0 & ~(2 * BKS - 1))) + '
+            '(size_t)((c0 / BKS) & 1) * 8 * p.k_total, sbase + q * 128 * 64);')
+        sub('            const int e = c0 + dchunk * EPC;\n            const bool ok = e < p.c_in && roff[pb] >= 0;\n'
+            '            const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);\n'
+            '            glds16(src, sbase + BN * 64 + pb * 128 * 64);',
+            '            const int e = (c0 & ~(2 * BKS - 1)) + dchunk * EPC;\n'
+            '            const bool ok = e < p.c_in && roff[pb] >= 0;\n'
+            '            const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);\n'
+            '            glds16(src, sbase + BN * 64 + pb * 128 * 64);')
+open(path, 'w').write(s)
