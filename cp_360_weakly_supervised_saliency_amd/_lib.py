@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         'dtype', 'n_img', 'h_in', 'w_in', 'c_in', 'pix_stride', 'kh', 'kw', 'sy', 'sx',
         'h_out', 'w_out', 'c_out', 'pad_mode', 'pad', 'ld_out', 'out_coff', 'ld_res',
-        'relu', 'splits', 'tile_px')]
+        'relu', 'splits', 'tile_px', 'clip_resident')]
 
 
 class Cp360Error(RuntimeError):

@@ -45,6 +45,7 @@ struct ConvK {
     int pad_mode, pad, ld_out, out_coff, ld_res, relu, splits;
     int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
     int nt, mt, m_fast;
+    int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
 };
 
 template <typename T> struct Elem;
@@ -129,9 +130,11 @@ __device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
 template <typename T, int BN, int BM, int MJ, int NT, int LDS_BYTES>
 __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds, f32x4 (&acc)[4][MJ], int n0, int m0,
                                              int wch0 /* wave's first tile channel */,
-                                             int wrow0 /* wave's first tile row (pixel) */, int lane, int tid) {
+                                             int wrow0 /* wave's first tile row (pixel) */, int lane, int tid,
+                                             int rows_valid = BM /* tile rows that are output pixels */) {
     constexpr int EPC = Elem<T>::EPC;
-    constexpr int NH = (BM * (BN * (int)sizeof(T) + 16) <= LDS_BYTES) ? 1 : 2;   // channel halves
+    constexpr int NH = (BM * (BN * (int)sizeof(T) + 16) <= LDS_BYTES) ? 1                // channel slices
+                       : (BM * (BN / 2 * (int)sizeof(T) + 16) <= LDS_BYTES) ? 2 : 4;
     constexpr int HC = BN / NH;                            // channels per half
     constexpr int CPR = HC / EPC;                          // 16-byte chunks per tile row
     constexpr int S = HC * (int)sizeof(T) + 16;            // LDS row stride (bytes), 16-byte aligned
@@ -156,7 +159,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
                     const int q = q0 + u * NT;
                     const int row = q / CPR, c = q - row * CPR;
                     const int m = m0 + row, n = nh0 + c * EPC;
-                    const bool ok = q < BM * CPR && m < p.M && n < p.c_out;
+                    const bool ok = q < BM * CPR && row < rows_valid && m < p.M && n < p.c_out;
                     r[u] = *reinterpret_cast<const u32x4*>(ok ? res + (size_t)m * p.ld_res + n
                                                               : reinterpret_cast<const T*>(g_zero16));
                 }
@@ -212,7 +215,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
                 const int q = q0 + u * NT;
                 const int row = q / CPR, c = q - row * CPR;
                 const int m = m0 + row, n = nh0 + c * EPC;
-                if (q < BM * CPR && m < p.M && n < p.c_out)
+                if (q < BM * CPR && row < rows_valid && m < p.M && n < p.c_out)
                     *reinterpret_cast<u32x4*>(outp + (size_t)m * p.ld_out + p.out_coff + n) = r[u];
             }
         }
@@ -949,6 +952,298 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     }
 }
 
+// ------------------------------------------------------------------ clip-resident ConvLSTM convolution
+// CubePad(1) + 3x3 convolution on 7x7 cube faces (model/clstm.py:56-64 at the 224-pixel cube size).
+// CubePad only ever copies from the other faces of the SAME cube (cube_pad.py:114-216), so the nine
+// taps of an output pixel gather from the 6*49 = 294 pixels of its own clip - exactly one 304-row
+// tile.  The generic kernels re-fetch the activation rows of every tap from L2 (LDS-DMA loads never
+// hit L1: TCP_TCC_READ_REQ == TCP_TOTAL_CACHE_ACCESSES in profiles/), and the L2 -> LDS fill, not the
+// MFMA pipe, bounds them (profiles/r01_pmc_korder.txt).  Here
+//   * the packed weights are channel-major ([n][c / 64B][tap][64B], cp360_conv_desc.clip_resident):
+//     the nine taps of a 64-byte channel block are consecutive sub-steps;
+//   * the 64-byte channel block of ALL 294 pixels of the clip is brought into LDS ONCE (19 KiB, three
+//     buffers) and every tap's B fragments are read from it through a per-(tap, row) source-row table:
+//     a tap is a row permutation of the resident tile;
+//   * only the weight stream (16 KiB per sub-step, six-stage ring = five sub-steps of prefetch) is
+//     DMA'd per sub-step: the fill per sub-step drops from 35 KiB to 16 + 19/9 = 18 KiB.
+// The resident tile has its own swizzle: chunk c of row r sits at chunk c ^ (2 * ((r >> 2) & 1)).  A
+// tap reads 16 CONSECUTIVE source rows starting anywhere (interior pixels: row + (ky-1)*7 + (kx-1)), and
+// with this function every 16-lane ds_read_b128 group still covers 16 distinct 16-byte slots of the
+// bank row for any start (the ring's (-(r >> 2)) & 3 is conflict-free only for starts that are
+// multiples of 16: 9.6e7 conflict cycles per launch measured with it, profiles/).
+// Tile / wave layout and the half-sub-step stagger are those of the 256x304 ring kernel.
+__device__ __forceinline__ int clip_swz(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n);   // s_waitcnt vmcnt(min(n, N)), n wave-uniform
+template <> __device__ __forceinline__ void wait_vmcnt_upto<0>(int) { wait_vmcnt<0>(); }
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    if (n >= N) wait_vmcnt<N>();
+    else wait_vmcnt_upto<N - 1>(n);
+}
+
+struct ClipGeom {
+    static constexpr int BN = 256, BM = 304, NW = 6, NA = 2;
+    static constexpr int WSTAGE = BN * 64;                       // 16 KiB of weights per sub-step
+    static constexpr int ATILE = BM * 64;                        // 19 KiB: one channel block of the clip
+    static constexpr int TAB_ROW = 32;                           // bytes per (tap, wave group, lane row): 10 u16 + pad
+    static constexpr int TAB_BYTES = 9 * 2 * 16 * TAB_ROW;
+    static constexpr int OFF_ACT = NW * WSTAGE;
+    static constexpr int OFF_TAB = OFF_ACT + NA * ATILE;
+    static constexpr int LDS_BYTES = OFF_TAB + TAB_BYTES;        // 146,432 B
+};
+
+template <typename T, int MJ, int JH, bool LAG>
+__device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, const int n0, const int clip, const int split,
+                                          const int wave, const int lane, const int tid, const int wch0, const int grp) {
+    typedef ClipGeom G;
+    constexpr int BN = G::BN, BM = G::BM;
+    constexpr int EPC = Elem<T>::EPC;
+    constexpr int BKS = 4 * EPC;                               // K elements per sub-step (64 bytes)
+    constexpr int TAPS = 9;
+    const int wrow0 = grp * 160;
+    const bool xw = wave < 3;                                  // waves 0-2 carry the 48 rows past 256 of an activation tile
+    const int m0 = clip * p.clip_rows;
+
+    // DMA role (as in the ring kernel): 16 rows x 4 chunks per wave-instruction, source-side swizzle
+    const int drow = 16 * wave + (lane >> 2);
+    const int dchunk = (lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3);   // weight stages: ring swizzle
+    const int dchunk_a = (lane & 3) ^ clip_swz(drow);                            // activation tile (drow + 128 q: same)
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + drow) * p.k_total + dchunk * EPC;
+    const size_t wpass = (size_t)128 * p.k_total;
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;
+    int aoff[3];                                               // element offset of this lane's pixel rows (fixed)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int r = drow + 128 * q;
+        aoff[q] = (r < p.clip_rows && (q < 2 || xw)) ? (m0 + r) * p.pix_stride : -1;
+    }
+
+    const int s_begin = split * p.sub_per_split;
+    const int s_end = min(p.nsub, s_begin + p.sub_per_split);
+    const int nloc = s_end - s_begin;
+    const int cb0 = s_begin / TAPS;
+    int tap = s_begin - cb0 * TAPS;                            // compute position: tap, activation buffer
+    int abuf = cb0 % G::NA;                                    // NA = 2: the tile of block cb+1 lands while block cb is computed
+    int next_act = cb0;                                        // next channel block to bring in
+    int woff = s_begin * BKS;                                  // DMA position in the packed row (linear)
+
+    auto issue_w = [&](int q, unsigned sbase) __attribute__((always_inline)) {
+        glds16(wbase + q * wpass + woff, sbase + q * 128 * 64);
+    };
+    auto issue_a = [&](int q) __attribute__((always_inline)) {   // pass q of channel block next_act
+        const int e = next_act * BKS + dchunk_a * EPC;
+        const bool ok = e < p.c_in && aoff[q] >= 0;
+        const T* src = ok ? in + (size_t)aoff[q] + e : reinterpret_cast<const T*>(g_zero16);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)(G::OFF_ACT + (next_act % G::NA) * G::ATILE));
+        glds16(src, dst + q * 128 * 64);
+    };
+    auto issue_act_tile = [&]() __attribute__((always_inline)) {
+        issue_a(0);
+        issue_a(1);
+        if (xw) issue_a(2);
+        ++next_act;
+    };
+
+    f32x4 acc[4][MJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nloc > 0) {
+        const int lrow = lane & 15, lchunk = lane >> 4;
+        const unsigned cx = (unsigned)lchunk << 4;             // entry ^ cx = swizzled chunk address
+        const unsigned char* tabp = lds + G::OFF_TAB + (grp * 16 + lrow) * G::TAB_ROW;
+        // source-row entries of the NEXT head (10 u16: bytes 0-15 = blocks 0-7, 16-19 = blocks 8-9)
+        u32x4 e03;
+        unsigned e4;
+        auto load_ent = [&](int t) __attribute__((always_inline)) {
+            e03 = *reinterpret_cast<const u32x4*>(tabp + t * (2 * 16 * G::TAB_ROW));
+            e4 = *reinterpret_cast<const unsigned*>(tabp + t * (2 * 16 * G::TAB_ROW) + 16);
+        };
+        auto ent = [&](int j) __attribute__((always_inline)) -> unsigned {
+            const unsigned w = j < 2 ? e03.x : j < 4 ? e03.y : j < 6 ? e03.z : j < 8 ? e03.w : e4;
+            return ((j & 1) ? (w >> 16) : (w & 0xffffu)) ^ cx;
+        };
+        // prologue: the first activation tile - and the second one when the range starts inside a
+        // channel block, because the tap-0 request of the next block would come too late - (older than
+        // every weight DMA), then NW-1 weight stages
+        issue_act_tile();
+        if (tap != 0) issue_act_tile();
+        {
+            const unsigned sb = __builtin_amdgcn_readfirstlane(lds_wave);
+            issue_w(0, sb); issue_w(1, sb);
+#pragma unroll
+            for (int k = 1; k < G::NW - 1; ++k)
+                if (nloc > k) { woff += BKS; issue_w(0, sb + k * G::WSTAGE); issue_w(1, sb + k * G::WSTAGE); }
+        }
+        load_ent(tap);
+        int stage = 0;
+        u32x4 a[4], b[JH];
+        if (LAG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < JH; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
+        }
+        // HEAD / TAIL / stagger: see ring_body.  New here: B fragments come from the resident
+        // activation tile through the entries; at tap 0 the tile of the NEXT channel block is
+        // requested (into the other buffer, whose block ended before this sub-step's first barrier).
+#define CP360_CLIP_HEAD(REFILL)                                                                            \
+        {                                                                                                  \
+            const unsigned char* As = lds + stage * G::WSTAGE;                                             \
+            const unsigned char* Ab = lds + G::OFF_ACT + abuf * G::ATILE;                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
+                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \
+            _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                 \
+                b[j] = *reinterpret_cast<const u32x4*>(Ab + ent(j));                                       \
+            unsigned sbase = 0;                                                                            \
+            if (REFILL) {                                                                                  \
+                woff += BKS;                                                                               \
+                sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)(stage == 0 ? G::NW - 1 : stage - 1) * G::WSTAGE); \
+            }                                                                                              \
+            const bool trig = tap == 0;                                                                    \
+            _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                               \
+                if (j == 0 && trig) issue_act_tile();                                                      \
+                if (REFILL && j < 2) issue_w(j, sbase);                                                    \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);         \
+                if (JH + j < MJ) b[j] = *reinterpret_cast<const u32x4*>(Ab + ent(JH + j));                 \
+            }                                                                                              \
+            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \
+            ++tap;                                                                                         \
+            if (tap == TAPS) {                                                                             \
+                tap = 0;                                                                                   \
+                abuf = abuf == G::NA - 1 ? 0 : abuf + 1;                                                   \
+            }                                                                                              \
+            load_ent(tap);                                                                                 \
+        }
+#define CP360_CLIP_TAIL()                                                                                  \
+        {                                                                                                  \
+            _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                                \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j - JH]);    \
+        }
+#define CP360_CLIP_STEP(REFILL)                                                                            \
+        {                                                                                                  \
+            if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            if (!LAG) CP360_CLIP_TAIL() else CP360_CLIP_HEAD(REFILL)                                       \
+        }
+        // vmcnt: DMAs complete in issue order.  Before sub-step `it` its weight stage (issued NW-1
+        // heads earlier) must have landed; younger than it are the weight stages of the next NW-2
+        // sub-steps (2 DMAs each) and an activation tile (2 or 3 DMAs, issued in front of its head's
+        // weight DMAs) if one was requested in one of the last NW-2 heads, i.e. iff the compute tap is
+        // in 1 .. NW-2 and that head belongs to this range.
+        constexpr int YW = 2 * (G::NW - 2);
+        const int na = xw ? 3 : 2;
+        int it = 0;
+        for (; it + G::NW - 1 < nloc; ++it) {
+            const bool act_young = tap >= 1 && tap <= G::NW - 2 && it >= tap;
+            if (!act_young) wait_vmcnt<YW>();
+            else if (xw)    wait_vmcnt<YW + 3>();
+            else            wait_vmcnt<YW + 2>();
+            CP360_CLIP_STEP(true)
+        }
+        for (; it < nloc; ++it) {                   // drain: no weight refill
+            const bool act_young = tap >= 1 && tap <= G::NW - 2 && it >= tap;
+            const int young = 2 * min(G::NW - 2, nloc - 1 - it);
+            // an activation tile requested during the drain may be younger than fewer weight stages
+            // than the count assumes: wait for everything then (at most NW-2 sub-steps, once)
+            if (act_young && young < YW) wait_vmcnt<0>();
+            else wait_vmcnt_upto<YW + 3>(young + (act_young ? na : 0));
+            CP360_CLIP_STEP(false)
+        }
+        if (LAG) CP360_CLIP_TAIL()
+#undef CP360_CLIP_STEP
+#undef CP360_CLIP_HEAD
+#undef CP360_CLIP_TAIL
+    }
+
+    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
+        (p.ld_res % EPC == 0)) {
+        epilogue_lds<T, BN, BM, MJ, 512, G::LDS_BYTES>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid, p.clip_rows);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wch0 + i * 16 + nl;
+        if (n >= p.c_out) continue;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int row = wrow0 + j * 16 + ml;
+            if (row >= p.clip_rows) continue;
+            const int m = m0 + row;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.partial) {
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+            } else {
+                if (p.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (p.res) {
+                    float r[4];
+                    load4(reinterpret_cast<const T*>(p.res) + (size_t)m * p.ld_res + n, r);
+                    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+                }
+                if (p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+                store4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ld_out + p.out_coff + n, v);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
+    typedef ClipGeom G;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int n0, clip, split;
+    {   // XCD-aware mapping, clips fastest: the workgroups of one (channel tile, split) share the weight stream
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        clip = w % p.mt;
+        const int rest = w / p.mt;
+        n0 = (rest % p.nt) * G::BN;
+        split = rest / p.nt;
+    }
+    // ---- source-row table: entry(tap, group, lane row, block j) = LDS byte offset (row * 64 +
+    // swizzle bits) inside the resident tile of the pixel that tap `tap` of tile row
+    // group*160 + j*16 + lrow reads (through CubePad); rows past the clip read row 0 (discarded).
+    {
+        unsigned short* tab = reinterpret_cast<unsigned short*>(lds + G::OFF_TAB);
+        const int n = p.h_in, nn = n * n;
+        const CubePadGeom geom{n, 1, 1, 1, 1};
+        for (int idx = tid; idx < 9 * 2 * 16 * 10; idx += 512) {
+            const int j = idx % 10, lr = (idx / 10) % 16, g = (idx / 160) % 2, t = idx / 320;
+            const int row = g * 160 + j * 16 + lr;
+            int src = 0;
+            if (row < p.clip_rows && (g == 0 || j < 9)) {
+                const int f = row / nn, rem = row - f * nn;
+                const int y = rem / n, x = rem - y * n;
+                src = cubepad_src(f, y + t / 3, x + t % 3, geom);          // pixel index inside the clip
+            }
+            tab[((t * 2 + g) * 16 + lr) * (G::TAB_ROW / 2) + j] =
+                (unsigned short)(src * 64 + (clip_swz(src) << 4));
+        }
+        __syncthreads();
+    }
+    if (wave < 4) clip_body<T, 10, 5, false>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+    else          clip_body<T, 9, 5, true>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+}
+
 // ------------------------------------------------------------------ split-K finish
 template <typename T>
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ partial, int splits,
@@ -1030,14 +1325,27 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                                            T* __restrict__ packed, int c_out, int c_out_pad, int c_in,
-                                                           int c_pad, int kh, int kw, int stem_mode) {
+                                                           int c_pad, int kh, int kw, int stem_mode, int chan_major) {
     const int taps = kh * kw;
+    constexpr int BKS = 64 / (int)sizeof(T);          // elements per 64-byte sub-step
     const long long total = (long long)c_out_pad * taps * c_pad;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c_pad);
-        const long long t = idx / c_pad;
-        const int tap = (int)(t % taps), n = (int)(t / taps);
+        int c, tap, n;
+        if (chan_major) {   // [n][c / BKS][tap][BKS]   (c_pad is a multiple of BKS here)
+            const int e = (int)(idx % BKS);
+            long long t = idx / BKS;
+            tap = (int)(t % taps);
+            t /= taps;
+            const int cpb = c_pad / BKS;
+            c = (int)(t % cpb) * BKS + e;
+            n = (int)(t / cpb);
+        } else {            // [n][tap][c_pad]
+            c = (int)(idx % c_pad);
+            const long long t = idx / c_pad;
+            tap = (int)(t % taps);
+            n = (int)(t / taps);
+        }
         float v = 0.f;
         if (n < c_out) {
             if (stem_mode) {   // desc kh=7, kw=1, c_in=32: k = kx*4 + ch of a [c_out,3,7,7] filter
@@ -1061,6 +1369,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ------------------------------------------------------------------ host side
 static int elem_bytes(int dtype) { return dtype == CP360_F32 ? 4 : ((dtype == CP360_BF16 || dtype == CP360_F16) ? 2 : 0); }
 static int bk_of(int dtype) { return 128 / elem_bytes(dtype); }
+// K padding per tap: a 128-byte step for the tap-major layout, a 64-byte sub-step for the channel-major one
+static int c_pad_of(const cp360_conv_desc* d) {
+    const int unit = d->clip_resident ? bk_of(d->dtype) / 2 : bk_of(d->dtype);
+    return (d->c_in + unit - 1) / unit * unit;
+}
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 static int check_desc(const cp360_conv_desc* d) {
@@ -1072,6 +1385,12 @@ static int check_desc(const cp360_conv_desc* d) {
     const int epc = 16 / elem_bytes(d->dtype);
     if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 256 && d->tile_px != 304)
         return CP360_ERR_BAD_SHAPE;
+    if (d->clip_resident != 0 && d->clip_resident != 1) return CP360_ERR_BAD_SHAPE;
+    // clip-resident kernel: CubePad(1) + 3x3 stride 1 on faces whose cube (6 n^2 pixels) fits one 304-row tile
+    if (d->clip_resident && !(d->pad_mode == 1 && d->pad == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 &&
+                              d->h_in == d->w_in && 6 * d->h_in * d->w_in <= 304 && d->c_out >= 256 &&
+                              d->pix_stride >= d->c_in && d->tile_px == 0))
+        return CP360_ERR_UNSUPPORTED;
     if (d->c_in % epc != 0 || d->c_out % 4 != 0 || d->ld_out % 4 != 0 || d->out_coff % 4 != 0 || d->ld_res % 4 != 0)
         return CP360_ERR_ALIGN;
     if (d->ld_out < d->c_out + d->out_coff) return CP360_ERR_BAD_SHAPE;
@@ -1092,8 +1411,7 @@ static int check_desc(const cp360_conv_desc* d) {
 
 extern "C" size_t cp360_conv_packed_bytes(const cp360_conv_desc* d) {
     if (check_desc(d)) return 0;
-    const int c_pad = round_up(d->c_in, bk_of(d->dtype));
-    return (size_t)round_up(d->c_out, 256) * d->kh * d->kw * c_pad * elem_bytes(d->dtype);
+    return (size_t)round_up(d->c_out, 256) * d->kh * d->kw * c_pad_of(d) * elem_bytes(d->dtype);
 }
 
 extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
@@ -1135,6 +1453,25 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
 }
 
 static ConvPlan plan_of(const cp360_conv_desc* d) {
+    if (d->clip_resident) {
+        // one 256-channel x clip tile per workgroup, 64-byte sub-steps; about 0.9 us per sub-step
+        const int wgs = ((d->c_out + 255) / 256) * (d->n_img / 6);
+        const int nsub = 9 * (c_pad_of(d) / (bk_of(d->dtype) / 2));
+        const double t_sub = d->dtype == CP360_F32 ? 2.7 : 0.9;
+        const long long M = (long long)d->n_img * d->h_out * d->w_out;
+        ConvPlan best{256, 304, 256, 1, 0.0};
+        for (int s = 1; s <= 32; ++s) {
+            if (s > 1 && nsub / s < 16) break;
+            const int rounds = (wgs * s + 255) / 256;
+            double cost = (double)rounds * (4.0 + (double)((nsub + s - 1) / s) * t_sub);
+            if (s > 1) cost += 4.0 + (double)s * (double)M * d->c_out * 8.0 / 4.0e6;
+            if (s == 1 || cost < best.cost) {
+                best.splits = s;
+                best.cost = cost;
+            }
+        }
+        return best;
+    }
     if (d->c_out <= 64) return plan_candidate(d, 64, 256, 512, 1.5);
     if (d->c_out < 256) return plan_candidate(d, 128, 128, 512, 1.5);
     ConvPlan best = plan_candidate(d, 256, 256, 256, 2.2);
@@ -1179,7 +1516,8 @@ extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_
     if (rc) return rc;
     if (!w_oihw || !packed) return CP360_ERR_NULL;
     if (stem_mode && !(d->kh == 7 && d->kw == 1 && d->c_in == 32)) return CP360_ERR_UNSUPPORTED;
-    const int c_pad = round_up(d->c_in, bk_of(d->dtype));
+    if (stem_mode && d->clip_resident) return CP360_ERR_UNSUPPORTED;
+    const int c_pad = c_pad_of(d);
     const int c_out_pad = round_up(d->c_out, 256);
     const long long total = (long long)c_out_pad * d->kh * d->kw * c_pad;
     long long blocks = (total + 255) / 256;
@@ -1187,13 +1525,13 @@ extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == CP360_F32)
         hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
-                           (float*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
+                           (float*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident);
     else if (d->dtype == CP360_F16)
         hipLaunchKernelGGL((pack_weights_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
-                           (f16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
+                           (f16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident);
     else
         hipLaunchKernelGGL((pack_weights_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
-                           (bf16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode);
+                           (bf16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident);
     CP360_CHECK_HIP();
     return CP360_OK;
 }
@@ -1230,12 +1568,26 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     k.hw_out = d->h_out * d->w_out;
     k.M = d->n_img * k.hw_out;
     const int bk = bk_of(d->dtype);
-    k.c_pad = round_up(d->c_in, bk);
-    k.steps_per_tap = k.c_pad / bk;
+    k.c_pad = c_pad_of(d);
+    k.steps_per_tap = k.c_pad / bk;                              // 128-byte steps (tap-major layout only)
     k.nsteps = d->kh * d->kw * k.steps_per_tap;
     k.steps_per_split = (k.nsteps + d->splits - 1) / d->splits;
     k.k_total = d->kh * d->kw * k.c_pad;
+    k.clip_rows = 6 * d->h_out * d->w_out;
+    k.nsub = k.k_total / (bk / 2);
+    k.sub_per_split = (k.nsub + d->splits - 1) / d->splits;
     hipStream_t st = (hipStream_t)stream;
+    if (d->clip_resident) {
+        k.nt = (k.c_out + 255) / 256;
+        k.mt = d->n_img / 6;
+        k.m_fast = 1;
+        dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
+        if (d->dtype == CP360_F32) hipLaunchKernelGGL((conv_clip_kernel<float>), grid, dim3(512), 0, st, k);
+        else if (d->dtype == CP360_F16) hipLaunchKernelGGL((conv_clip_kernel<f16_raw>), grid, dim3(512), 0, st, k);
+        else hipLaunchKernelGGL((conv_clip_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+        CP360_CHECK_HIP();
+        return CP360_OK;
+    }
     const bool narrow = d->c_out <= 64;
     int bn_ = 0, bm_ = 0, slots_ = 0;
     if (d->c_out >= 256) tile_of(d, &bn_, &bm_, &slots_);

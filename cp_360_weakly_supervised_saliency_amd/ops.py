@@ -161,7 +161,7 @@ class Conv:
     """
 
     def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, relu=False, dtype=torch.float32,
-                 device='cuda', stem=False):
+                 device='cuda', stem=False, clip_resident=None):
         self.dtype = dtype
         self.device = torch.device(device)
         self.stride = int(stride)
@@ -169,30 +169,53 @@ class Conv:
         self.relu = bool(relu)
         self.stem = bool(stem)
         self.tag = 'conv'
-        w = weight.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        self.c_out, self.c_in_w, self.kh_w, self.kw_w = w.shape
+        self._w_src = weight.detach()          # packed lazily per layout (no copy kept: the module owns it)
+        self.c_out, self.c_in_w, self.kh_w, self.kw_w = weight.shape
         if stem:
             assert (self.c_in_w, self.kh_w, self.kw_w) == (3, 7, 7)
             self.c_in, self.kh, self.kw, self.pix_stride = 32, 7, 1, 4
         else:
             self.c_in, self.kh, self.kw, self.pix_stride = self.c_in_w, self.kh_w, self.kw_w, self.c_in_w
         self.bias = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        sc = None if scale is None else scale.detach().to(device=self.device, dtype=torch.float32).contiguous()
-        d = self._desc(6, max(self.kh, 8), max(self.kw, 8) if not stem else 16, 1)
-        nbytes = lib().cp360_conv_packed_bytes(C.byref(d))
-        if nbytes == 0:
-            raise ValueError("unsupported convolution geometry for libcp360")
-        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        check(lib().cp360_conv_pack_weights(C.byref(d), ptr(w), ptr(sc), ptr(self.packed), 1 if stem else 0, stream()))
+        self._scale = None if scale is None else scale.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        # cp360_conv_desc.clip_resident: CubePad(1) + 3x3 stride 1 with c_out >= 256 may run on the
+        # clip-resident kernel when the faces turn out to be <= 7x7 at call time (ConvLSTM at cube 224,
+        # layer4 conv2); it reads a channel-major packing, made on first use
+        if clip_resident is None:
+            clip_resident = (not stem and self.pad == 1 and self.stride == 1 and self.kh == 3 and self.kw == 3
+                             and self.c_out >= 256)
+        self.clip_resident_ok = bool(clip_resident)
+        self._packed = {}
         self._partial = None
         self._splits_cache = {}
+
+    def packed_for(self, clip_resident):
+        """Packed weights in the layout of cp360_conv_desc.clip_resident (0 / 1), built on first use."""
+        t = self._packed.get(clip_resident)
+        if t is None:
+            d = self._desc(6, 7, 7, 1, clip_resident=clip_resident) if clip_resident else \
+                self._desc(6, max(self.kh, 8), max(self.kw, 8) if not self.stem else 16, 1)
+            nbytes = lib().cp360_conv_packed_bytes(C.byref(d))
+            if nbytes == 0:
+                raise ValueError("unsupported convolution geometry for libcp360")
+            w = self._w_src.to(device=self.device, dtype=torch.float32).contiguous()
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            check(lib().cp360_conv_pack_weights(C.byref(d), ptr(w), ptr(self._scale), ptr(t), 1 if self.stem else 0,
+                                                stream()))
+            self._packed[clip_resident] = t
+        return t
+
+    @property
+    def packed(self):
+        return self.packed_for(0)               # the tap-major packing every kernel but the clip-resident one reads
 
     def out_hw(self, h_in, w_in):
         p2 = 2 * self.pad
         return (h_in + p2 - self.kh) // self.stride + 1, \
                ((w_in + p2 - self.kw_w) // self.stride + 1 if self.stem else (w_in + p2 - self.kw) // self.stride + 1)
 
-    def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None, tile_px=0):
+    def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None, tile_px=0,
+              clip_resident=0):
         d = ConvDesc()
         d.dtype = dtype_code(self.dtype)
         d.n_img, d.h_in, d.w_in = n_img, h_in, w_in
@@ -206,6 +229,7 @@ class Conv:
         d.relu = int(self.relu if relu is None else relu)
         d.splits = splits
         d.tile_px = tile_px
+        d.clip_resident = clip_resident
         return d
 
     def nsteps(self):
@@ -213,7 +237,7 @@ class Conv:
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
 
     def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None,
-                 tile_px=0):
+                 tile_px=0, clip_resident=None):
         """x [n_img, h, w, c] NHWC (for the stem: the materialised CubePad(3) output
         [n_img, h+6, w+6, 4]).  Returns [n_img, h_out, w_out, c_out] in self.dtype, or
         with raw_f32=True the (partial [splits, M, c_out] f32, splits) pair whose
@@ -231,13 +255,19 @@ class Conv:
         ld_out = self.c_out if out is None else out.shape[3]
         ld_res = 0 if residual is None else residual.shape[3]
         L = lib()
+        # clip-resident kernel: whole cubes of <= 304 pixels (faces <= 7x7), no forced tile
+        cr = self.clip_resident_ok if clip_resident is None else bool(clip_resident)
+        cr = int(cr and h_in == w_in and 6 * h_in * w_in <= 304 and n_img % 6 == 0 and tile_px == 0)
+        if clip_resident and not cr:
+            raise ValueError("clip_resident needs CubePad(1)+3x3 stride 1 on faces of at most 7x7")
         if splits is None:
-            key = (n_img, h_in, w_in)
+            key = (n_img, h_in, w_in, cr)
             splits = self._splits_cache.get(key)
             if splits is None:
-                splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1)))
+                splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1, clip_resident=cr)))
                 self._splits_cache[key] = splits
-        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res, tile_px=tile_px)
+        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res, tile_px=tile_px, clip_resident=cr)
+        packed = self.packed_for(cr)
         def forward(*a):
             if LAUNCH_TIMER is None:
                 return L.cp360_conv_forward(*a)
@@ -249,12 +279,12 @@ class Conv:
             if partial_buf is not None:          # caller-owned destination for the raw sums
                 if partial_buf.numel() < need or partial_buf.dtype != torch.float32:
                     raise ValueError("partial_buf too small")
-                check(forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
+                check(forward(C.byref(d), ptr(x), ptr(packed), None, None, None,
                                            ptr(partial_buf), stream()))
                 return partial_buf, splits
             if self._partial is None or self._partial.numel() < need:
                 self._partial = torch.empty(need, dtype=torch.float32, device=x.device)
-            check(forward(C.byref(d), ptr(x), ptr(self.packed), None, None, None,
+            check(forward(C.byref(d), ptr(x), ptr(packed), None, None, None,
                                        ptr(self._partial), stream()))
             if raw_f32:
                 return self._partial, splits
@@ -265,7 +295,7 @@ class Conv:
             return out
         if out is None:
             out = torch.empty((n_img, h_out, w_out, self.c_out), dtype=self.dtype, device=x.device)
-        check(forward(C.byref(d), ptr(x), ptr(self.packed), ptr(self.bias), ptr(residual), ptr(out),
+        check(forward(C.byref(d), ptr(x), ptr(packed), ptr(self.bias), ptr(residual), ptr(out),
                                    None, stream()))
         return out
 

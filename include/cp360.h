@@ -150,6 +150,13 @@ typedef struct {
                          256 (tuning, tests): 128 / 256 / 304 force the pixel tile
                          of the 8-wave 256-channel kernels, 64 forces the 4-wave
                          128x128 kernel                                           */
+    int clip_resident;/* 1: CubePad(1) + 3x3 stride-1 convolution on cube faces small
+                         enough that a whole cube (6 n^2 <= 304 pixels, n <= 7: the
+                         ConvLSTM of model/clstm.py at cube size 224) is one tile:
+                         the packed weights are channel-major ([c / 64 B][tap]) and
+                         every tap reads the clip's activations from an LDS-resident
+                         tile (cubepad halo never leaves the cube).  Must be the same
+                         at pack and forward time; other geometries: UNSUPPORTED    */
 } cp360_conv_desc;
 
 /* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */

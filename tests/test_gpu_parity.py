@@ -237,6 +237,33 @@ def test_wide_conv_forced_pixel_tiles(tile_px, prec, splits):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('n', [7, 5, 3])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('splits', [1, 3, 7])
+def test_clip_resident_conv(n, prec, splits):
+    """cp360_conv_desc.clip_resident: CubePad(1) + 3x3 on faces <= 7x7 with the clip's activations
+    resident in LDS and the taps served as row permutations (channel-major packed weights).  3 clips
+    (cubes) of 6 n^2 pixels; c_in = 104: K tail inside a 64-byte channel block (bf16) / exact (fp32);
+    c_out = 264: ragged channel tile; splits 3 and 7 cut inside channel blocks; residual + ReLU run the
+    LDS epilogue with rows past the clip masked."""
+    dt = _TDT[prec]
+    n_img, cin, cout, k = 18, 104, 264, 3
+    x = hashrng.normal(9400 + n, (n_img, cin, n, n))
+    w = hashrng.normal(9401, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
+    bias = hashrng.normal(9403, (cout,), 0, 0.1)
+    res = hashrng.normal(9404 + n, (n_img, cout, n, n))
+    rb = (lambda a: torch.from_numpy(a).to(dt).float().numpy()) if prec != 'fp32' else (lambda a: a)
+    want = _conv_ref(rb(x), rb(w), None, bias, 1, 1, True, rb(res))
+    conv = ops.Conv(torch.from_numpy(w), None, torch.from_numpy(bias), 1, 1, True, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    rt = ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
+    got = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits, clip_resident=True), out_dtype=torch.float32).cpu().numpy()
+    assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
+    # and it equals the generic (tap-major) kernel on the same operands up to summation order
+    gen = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits, clip_resident=False), out_dtype=torch.float32).cpu().numpy()
+    assert rel_err(got, gen) <= _TOL[prec]
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 def test_stem_conv_and_maxpool(prec):
     dt = _TDT[prec]

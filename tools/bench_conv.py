@@ -18,6 +18,7 @@ ap.add_argument('--only', default='')
 ap.add_argument('--splits', type=int, default=0)
 ap.add_argument('--residual', action='store_true', help='add a residual input (ResNet conv3)')
 ap.add_argument('--tile-px', type=int, default=0)
+ap.add_argument('--clip-resident', type=int, default=-1, help='1/0 force the clip-resident kernel on/off')
 args = ap.parse_args()
 dt = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.precision]
 dev = 'cuda'
@@ -47,6 +48,8 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     kw = {'splits': args.splits} if args.splits else {}
     if args.tile_px:
         kw['tile_px'] = args.tile_px
+    if args.clip_resident >= 0 and k == 3 and n <= 7 and cout >= 256:
+        kw['clip_resident'] = bool(args.clip_resident)
     if args.residual:
         ho_ = (n + 2 * pad - k) // s + 1
         kw['residual'] = torch.randn(n_img, ho_, ho_, cout, device=dev).to(dt)
@@ -62,6 +65,6 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     ho = y.shape[1]
     flops = 2.0 * n_img * ho * ho * cout * cin * k * k
     M = n_img * ho * ho
-    sp = args.splits or list(conv._splits_cache.values())[0]
+    sp = args.splits or list(conv._splits_cache.values())[-1]
     print('%s M=%7d N=%4d K=%5d splits=%d  %8.3f ms  %7.1f TFLOP/s' % (name, M, cout, cin * k * k, sp, ms, flops / ms / 1e9),
           flush=True)

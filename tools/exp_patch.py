@@ -34,6 +34,12 @@ for v in variants:
             '__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wave-uniform */) {')
         sub('glds16(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);',
             'glds16w(wbase + q * wpass + ((size_t)tap * p.c_pad + c0), sbase + q * 128 * 64);')
+    if v == 'clip_l2only':   # clip kernel: weights alias row 0, activation tiles from the zero page
+        sub('    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + drow) * p.k_total + dchunk * EPC;\n    const size_t wpass = (size_t)128 * p.k_total;\n    const unsigned lds_base = (unsigned)(size_t)lds;\n    const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;\n    int aoff[3];',
+            '    const T* wbase = reinterpret_cast<const T*>(p.w) + dchunk * EPC;\n    const size_t wpass = 0;\n    const unsigned lds_base = (unsigned)(size_t)lds;\n    const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;\n    int aoff[3];')
+        sub('const bool ok = e < p.c_in && aoff[q] >= 0;', 'const bool ok = false;')
+    if v == 'clip_nogather':   # clip kernel: B fragments from identity rows (no table): isolates the gather cost
+        sub('return ((j & 1) ? (w >> 16) : (w & 0xffffu)) ^ cx;', 'return (unsigned)lds_swz64(wrow0 + j * 16 + lrow, lchunk) + 0u * w;')
     if v == 'fullline':
         sub('const int drow = 16 * wave + (lane >> 2);', 'const int drow = 16 * wave + (lane >> 3);')
         sub('const int dchunk = (lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3);', 'const int dchunk = lane & 7;')
