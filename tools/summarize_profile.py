@@ -38,7 +38,7 @@ def main():
     # dominant kernel launches in the trace: the ConvLSTM K=36000 convs are the longest conv_igemm<.,2,2> launches
     tr = find(os.path.join(src, 'trace'), '*kernel_trace.csv')
     if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm' in r['Kernel_Name']]
+        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm' in r['Kernel_Name'] or 'conv_clip' in r['Kernel_Name']]
         by_grid = {}
         for r in rows:
             key = (r['Kernel_Name'][:60], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
@@ -57,7 +57,10 @@ def main():
         f = find(os.path.join(src, name), '*counter_collection.csv')
         if not f:
             continue
-        rows = [r for r in csv.DictReader(open(f)) if 'conv_igemm' in r['Kernel_Name']]
+        rows = list(csv.DictReader(open(f)))
+        # the ConvLSTM convolutions: the clip-resident kernel when it ran, else the generic implicit GEMM
+        clip = [r for r in rows if 'conv_clip' in r['Kernel_Name']]
+        rows = clip if clip else [r for r in rows if 'conv_igemm' in r['Kernel_Name']]
         by = {}
         for r in rows:
             key = (r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size', ''), r.get('Grid_Size_Y', ''),
@@ -83,9 +86,12 @@ def main():
         lines.append('')
         lines.append('ConvLSTM conv launches (grid %s): FETCH_SIZE %.0f KiB (K=36000 launches; %.0f KiB over all three '
                      'convs), WRITE_SIZE %.0f KiB per launch -> HBM traffic (2*FETCH + WRITE)*1024 = %.1f MB per '
-                     'K=36000 launch (algorithmic: 297 MB packed weights + 19 MB activations + 56 MB slabs)'
+                     'K=36000 launch (algorithmic: 297 MB packed weights + 19 MB activations + 75 MB slabs (4 splits))'
                      % (key, fe, sum(fv) / len(fv), wr, traffic / 1e6))
     os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
+    if len(sys.argv) > 3 and 'conv_igemm_clstm_bytes_per_launch' in out:      # the file bench.py reads `traffic` from
+        json.dump({'conv_igemm_clstm_bytes_per_launch': out['conv_igemm_clstm_bytes_per_launch'],
+                   'source': os.path.basename(dst) + '.json'}, open(sys.argv[3], 'w'), indent=1)
     json.dump(out, open(dst + '.json', 'w'), indent=1)
     open(dst + '.md', 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
