@@ -40,6 +40,24 @@ for v in variants:
         sub('const bool ok = e < p.c_in && aoff[q] >= 0;', 'const bool ok = false;')
     if v == 'clip_nogather':   # clip kernel: B fragments from identity rows (no table): isolates the gather cost
         sub('return ((j & 1) ? (w >> 16) : (w & 0xffffu)) ^ cx;', 'return (unsigned)lds_swz64(wrow0 + j * 16 + lrow, lchunk) + 0u * w;')
+    if v == 'narrow_noload':   # 4-wave kernels: activations from the zero page, weight rows alias row 0
+        sub('const bool ok_ = kval_ && roff[pb] >= 0;', 'const bool ok_ = false;')
+        sub('const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + row0) * p.k_total + chunk * EPC;\n    const size_t wpass = (size_t)32 * p.k_total;',
+            'const T* wbase = reinterpret_cast<const T*>(p.w) + chunk * EPC;\n    const size_t wpass = 0;')
+    if v == 'nostore':         # LDS epilogue: skip the global stores of the output tile
+        sub('if (q < BM * CPR && row < rows_valid && m < p.M && n < p.c_out)\n                    *reinterpret_cast<u32x4*>(outp',
+            'if (q < BM * CPR && row < rows_valid && m < p.M && n < p.c_out && r[u].x == 0x12345678u)\n                    *reinterpret_cast<u32x4*>(outp')
+    if v == 'nores':           # LDS epilogue: residual tile from the zero page
+        sub('const bool ok = q < BM * CPR && row < rows_valid && m < p.M && n < p.c_out;', 'const bool ok = false;')
+    if v == 'ring_noload':     # ring kernel: all operands from L1-resident lines
+        sub('const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + drow) * p.k_total + dchunk * EPC;\n    const size_t wpass = (size_t)128 * p.k_total;\n    const unsigned lds_base = (unsigned)(size_t)lds;\n    const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;          // this wave',
+            'const T* wbase = reinterpret_cast<const T*>(p.w) + dchunk * EPC;\n    const size_t wpass = 0;\n    const unsigned lds_base = (unsigned)(size_t)lds;\n    const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;          // this wave')
+        sub('const bool ok = e < p.c_in && roff[pb] >= 0;', 'const bool ok = false;')
+    if v == 'ring_noepi':      # ring kernel: no epilogue at all (one impossible store keeps the accumulators live)
+        sub('        epilogue_lds<T, BN, BM, MJ, 512, G::template lds_bytes<T>()>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid);\n        return;',
+            '        if (acc[0][0][0] == 1.2345e-30f) p.out[0] = 1;\n        return;')
+    if v == 'ring_nok':        # ring kernel: skip the K loop (epilogue only)
+        sub('    const int nloc = s_end - s_begin;\n    const int sub_per_tap = 2 * p.steps_per_tap;', '    const int nloc = 0 * (s_end - s_begin);\n    const int sub_per_tap = 2 * p.steps_per_tap;')
     if v == 'fullline':
         sub('const int drow = 16 * wave + (lane >> 2);', 'const int drow = 16 * wave + (lane >> 3);')
         sub('const int dchunk = (lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3);', 'const int dchunk = lane & 7;')
