@@ -105,6 +105,9 @@ def main():
     ap.add_argument('--cube', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--frame-chunk', type=int, default=0, help='frames per static-stage group (0 = all)')
+    ap.add_argument('--source', default='', help='decoded frame size HxW: include the PIL-exact Lanczos resize (K0) in the step')
+    ap.add_argument('--static-only', action='store_true',
+                    help='BASELINE config C2: the static path only (equi -> cube -> ResNet-50 -> CAM); no roofline object')
     args = ap.parse_args()
 
     rank, world, local = cpdist.init_from_env()
@@ -119,17 +122,23 @@ def main():
 
     rs = synth.resnet50_state(seed=1)
     cs = synth.clstm_state(seed=2)
+    src_hw = tuple(int(v) for v in args.source.split('x')) if args.source else None
     eng = SaliencyEngine(rs, cs, (H, W), args.cube, clips=B, frames=T, precision=args.precision, device=dev,
-                         frame_chunk=args.frame_chunk or None)
+                         frame_chunk=args.frame_chunk or None, source_hw=src_hw)
     del rs, cs
     # this rank's clips (global clip id = rank*B + b), resident in HBM before timing
-    frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + rank * B + b, T, H, W)) for b in range(B)]).to(dev)
+    fh, fw = src_hw if src_hw else (H, W)
+    frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + rank * B + b, T, fh, fw)) for b in range(B)]).to(dev)
     n_clips = world * B
 
     timer = LaunchTimer()
     ops.LAUNCH_TIMER = timer
 
     def step():
+        if args.static_only:
+            with torch.no_grad():
+                cam = eng.static_stage(frames.reshape((B * T,) + tuple(frames.shape[2:])))
+            return cam.view(B, -1)[:, :8].float()
         sal = eng(frames)
         return cpdist.gather_maps(sal, n_clips, rank, world)
 
@@ -148,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer.active = False
     elapsed = cpdist.max_over_ranks(elapsed, dev)
-    assert out.shape[0] == n_clips and bool(torch.isfinite(out).all())
+    assert (args.static_only or out.shape[0] == n_clips) and bool(torch.isfinite(out).all())
 
     if rank == 0:
         frames_total = world * B * T * args.steps
@@ -175,9 +184,12 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'fp32': 'f32'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'C3/C4 per-GPU shard: %d clips x %d frames %dx%d u8 equi -> 6x%d^2 cube -> '
-                                   'CubePad ResNet-50 -> CAM -> ConvLSTM x%d -> cube_to_equi saliency %dx%d'
-                                   % (B, T, H, W, args.cube, T, 2 * eng.w, 4 * eng.w),
+            'config': {'workload': ('C2 static path only: %d x %d frames %dx%d u8 equi -> 6x%d^2 cube -> CubePad ResNet-50 -> CAM'
+                                    % (B, T, H, W, args.cube)) if args.static_only else
+                                   ('C3/C4 per-GPU shard: %d clips x %d frames %dx%d u8 equi -> 6x%d^2 cube -> '
+                                    'CubePad ResNet-50 -> CAM -> ConvLSTM x%d -> cube_to_equi saliency %dx%d'
+                                    % (B, T, H, W, args.cube, T, 2 * eng.w, 4 * eng.w))
+                                   + ((' (frames decoded at %dx%d, PIL-exact Lanczos resize included)' % (fh, fw)) if src_hw else ''),
                        'clips_per_gpu': B, 'frames_per_clip': T, 'equi': [H, W], 'cube_dim': args.cube,
                        'parallelism': 'clips sharded over %d GPU(s), 1 all-gather of maps' % world},
             'roofline': roof,

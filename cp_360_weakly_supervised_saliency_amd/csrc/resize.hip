@@ -1,0 +1,137 @@
+// K0: PIL-exact Lanczos resize of decoded frames.
+//
+// dataset_feat_extractor.py:119-142 resizes every frame with
+//   Image.fromarray(frame).convert('RGB').resize((1920, 960), resample=Image.LANCZOS)
+// before /255 and the cube projection.  Pillow's 8-bit resampler (src/libImaging/Resample.c):
+// separable, horizontal pass first, intermediate rounded to uint8, then the vertical pass; per output
+// index a window [xmin, xmin + n) of 22-bit fixed-point coefficients, int32 accumulation starting at
+// 1 << 21, arithmetic shift, clip to 0..255.  The coefficient tables are built on the host in double
+// precision exactly as Pillow does (cp360_resize_coeffs_host); the kernels only gather: HBM-bound
+// integer work, bit-exact by construction (tests compare with PIL itself).
+#include "common.h"
+#include <math.h>
+
+#define CP360_RESIZE_PRECISION_BITS (32 - 8 - 2)
+
+static double sinc_filter(double x) {
+    if (x == 0.0) return 1.0;
+    x = x * M_PI;
+    return sin(x) / x;
+}
+static double lanczos_filter(double x) {
+    if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+    return 0.0;
+}
+
+extern "C" int cp360_resize_ksize(int in_size, int out_size) {
+    if (in_size <= 0 || out_size <= 0) return CP360_ERR_BAD_SHAPE;
+    double filterscale = (double)in_size / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    return (int)ceil(3.0 * filterscale) * 2 + 1;
+}
+
+extern "C" int cp360_resize_coeffs_host(int in_size, int out_size, int* bounds, int* kk) {
+    if (!bounds || !kk) return CP360_ERR_NULL;
+    const int ksize = cp360_resize_ksize(in_size, out_size);
+    if (ksize < 0) return ksize;
+    double scale = (double)in_size / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 3.0 * filterscale, ss = 1.0 / filterscale;
+    double* w = (double*)malloc(sizeof(double) * ksize);
+    if (!w) return CP360_ERR_HIP;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            w[x] = lanczos_filter((x + xmin - center + 0.5) * ss);
+            ww += w[x];
+        }
+        int* k = kk + (size_t)xx * ksize;
+        for (int x = 0; x < ksize; ++x) {
+            double v = 0.0;
+            if (x < xmax) v = (ww != 0.0) ? w[x] / ww : w[x];
+            k[x] = v < 0 ? (int)(-0.5 + v * (1 << CP360_RESIZE_PRECISION_BITS))
+                         : (int)(0.5 + v * (1 << CP360_RESIZE_PRECISION_BITS));
+        }
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+    free(w);
+    return ksize;
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= CP360_RESIZE_PRECISION_BITS;
+    return (uint8_t)min(max(v, 0), 255);
+}
+
+// One pass along x (HORIZ) or y of u8 [F, H, W, 3] images: a thread produces the 3 channels of one
+// output pixel; neighbouring threads are neighbouring output columns (coalesced stores, overlapping
+// cached loads).
+template <bool HORIZ>
+__global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                          int ksize, int F, int h_in, int w_in, int h_out, int w_out) {
+    const long long total = (long long)F * h_out * w_out;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w_out);
+        const long long t = idx / w_out;
+        const int y = (int)(t % h_out), f = (int)(t / h_out);
+        const int o = HORIZ ? x : y;
+        const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+        const int* k = kk + (size_t)o * ksize;
+        const uint8_t* src = in + ((size_t)f * h_in * w_in + (HORIZ ? (size_t)y * w_in + lo : (size_t)lo * w_in + x)) * 3;
+        const size_t step = HORIZ ? 3 : (size_t)w_in * 3;
+        int s0 = 1 << (CP360_RESIZE_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int i = 0; i < n; ++i) {
+            const int c = k[i];
+            s0 += c * src[0];
+            s1 += c * src[1];
+            s2 += c * src[2];
+            src += step;
+        }
+        uint8_t* dst = out + (size_t)idx * 3;
+        dst[0] = clip8(s0);
+        dst[1] = clip8(s1);
+        dst[2] = clip8(s2);
+    }
+}
+
+extern "C" int cp360_resize_lanczos_u8(const void* in, void* out, void* tmp, int F, int h_in, int w_in, int h_out,
+                                       int w_out, const int* hbounds, const int* hkk, int hksize, const int* vbounds,
+                                       const int* vkk, int vksize, void* stream) {
+    if (!in || !out) return CP360_ERR_NULL;
+    if (F <= 0 || h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0) return CP360_ERR_BAD_SHAPE;
+    const bool need_h = w_out != w_in, need_v = h_out != h_in;
+    if (need_h && (!hbounds || !hkk || hksize <= 0)) return CP360_ERR_NULL;
+    if (need_v && (!vbounds || !vkk || vksize <= 0)) return CP360_ERR_NULL;
+    if (need_h && need_v && !tmp) return CP360_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    auto blocks_of = [](long long total) {
+        long long b = (total + 255) / 256;
+        return (unsigned)(b > 65535 * 4 ? 65535 * 4 : b);
+    };
+    if (!need_h && !need_v) {
+        if (hipMemcpyAsync(out, in, (size_t)F * h_in * w_in * 3, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return CP360_ERR_HIP;
+        return CP360_OK;
+    }
+    const uint8_t* cur = (const uint8_t*)in;
+    if (need_h) {       // [F, h_in, w_in] -> [F, h_in, w_out]
+        uint8_t* dst = need_v ? (uint8_t*)tmp : (uint8_t*)out;
+        hipLaunchKernelGGL((resize_pass_kernel<true>), dim3(blocks_of((long long)F * h_in * w_out)), dim3(256), 0, st, cur,
+                           dst, hbounds, hkk, hksize, F, h_in, w_in, h_in, w_out);
+        cur = dst;
+    }
+    if (need_v)         // [F, h_in, w_out] -> [F, h_out, w_out]
+        hipLaunchKernelGGL((resize_pass_kernel<false>), dim3(blocks_of((long long)F * h_out * w_out)), dim3(256), 0, st,
+                           cur, (uint8_t*)out, vbounds, vkk, vksize, F, h_in, w_out, h_out, w_out);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

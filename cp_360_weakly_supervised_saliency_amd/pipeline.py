@@ -1,6 +1,7 @@
 """End-to-end engine: equirectangular frames in HBM -> saliency maps in HBM.
 
-    frames u8 [B, T, H, W, 3]
+    frames u8 [B, T, H, W, 3]   (or [B, T, Hs, Ws, 3] decoded frames when source_hw is given:
+      K0 PIL-exact Lanczos resize to H x W              dataset_feat_extractor.py:131-133)
       K1 equi -> cube (+/255, ImageNet normalise)        dataset_feat_extractor.py:138-157
       K2 CubePad(3) -> K3 ResNet-50-cubic -> layer4      model/resnet_cubic.py:163-175
       K4 CAM (shifted fc weight as 1x1 conv)             class_activation_model.py:46-83
@@ -23,12 +24,13 @@ from .static_model.class_activation_model import cam_device
 from .temporal_model.test_temporal import ClipRunner
 from .utils.cube_to_equi import Cube2Equi
 from .utils.equi_to_cube import Equi2Cube
+from .utils.resize import LanczosResize
 
 
 class SaliencyEngine:
     def __init__(self, resnet_state, clstm_state, equi_hw=(1024, 2048), cube_dim=224, clips=1, frames=16,
                  precision='fp32', device='cuda', align_corners=False, cv_fixed_point=True,
-                 input_size=1000, hidden_size=1000, frame_chunk=None):
+                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None):
         self.device = torch.device(device)
         self.precision = precision
         self.dtype = _lib.precision_dtype(precision)
@@ -48,6 +50,11 @@ class SaliencyEngine:
         self.cell = ConvLSTMCell(input_size, hidden_size, precision=precision)
         self.cell.load_state_dict(_to_tensors(clstm_state))           # strict, as test_temporal.py:149
         self.cell.to(self.device).eval()
+        # decoded frames of another size are first resized as the reference does (PIL LANCZOS, K0)
+        self.source_hw = None if source_hw is None else (int(source_hw[0]), int(source_hw[1]))
+        self.resize = None
+        if self.source_hw is not None and self.source_hw != (self.H, self.W):
+            self.resize = LanczosResize(self.source_hw, (self.H, self.W), device=self.device)
         self.e2c = Equi2Cube(self.cube_dim, (self.H, self.W), device=self.device, cv_fixed_point=cv_fixed_point)
         self.c2e = Cube2Equi(self.w, align_corners=align_corners, device=self.device)
         self.runner = ClipRunner(self.cell, self.c2e, self.B, self.T, self.w)
@@ -61,7 +68,10 @@ class SaliencyEngine:
         cam_flat = self.cam.view(self.B * self.T, 6 * self.w * self.w, -1)
         for lo in range(0, F, self.frame_chunk):
             hi = min(F, lo + self.frame_chunk)
-            x4 = self.e2c.to_cube_batch(frames[lo:hi], out_dtype=self.dtype, layout='nhwc4')
+            chunk = frames[lo:hi]
+            if self.resize is not None:
+                chunk = self.resize(chunk)
+            x4 = self.e2c.to_cube_batch(chunk, out_dtype=self.dtype, layout='nhwc4')
             cam_device(x4, self.resnet, out=cam_flat[lo:hi])      # CAM conv writes the clip buffer directly
         return self.cam
 
@@ -74,7 +84,7 @@ class SaliencyEngine:
             B, T = frames.shape[:2]
             if (B, T) != (self.B, self.T):
                 raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
-            self.static_stage(frames.reshape(B * T, self.H, self.W, 3))
+            self.static_stage(frames.reshape((B * T,) + tuple(frames.shape[2:])))
             return self.temporal_stage()
 
 

@@ -117,6 +117,23 @@ int cp360_cube2equi(const float* x, const int8_t* face_map, const float* coord,
                     float* out_full, float* out_max, int B, int C, int w,
                     int layout, void* stream);
 
+/* ------------------------------------------------------------------ K0: PIL-exact Lanczos resize
+ * Replaces Image.fromarray(frame).convert('RGB').resize((w, h), resample=Image.LANCZOS) of
+ * static_model/dataset_feat_extractor.py:119-142 (the frame resize in front of the cube
+ * projection) for uint8 HWC frames, bit-exact with Pillow's 8-bit resampler.
+ */
+/* Taps per output index for a resize in_size -> out_size (Pillow's ksize); < 0: error. */
+int cp360_resize_ksize(int in_size, int out_size);
+/* HOST: Pillow's coefficient tables for one axis.  bounds int32 [out_size][2] = (first input
+ * index, tap count), kk int32 [out_size][ksize] 22-bit fixed point.  Returns ksize. */
+int cp360_resize_coeffs_host(int in_size, int out_size, int* bounds, int* kk);
+/* in u8 [F, h_in, w_in, 3] -> out u8 [F, h_out, w_out, 3] (device).  Tables are DEVICE copies of
+ * cp360_resize_coeffs_host(w_in, w_out) / (h_in, h_out); tmp u8 [F, h_in, w_out, 3] is needed
+ * when both axes change (horizontal pass first, as Pillow). */
+int cp360_resize_lanczos_u8(const void* in, void* out, void* tmp, int F, int h_in, int w_in,
+                            int h_out, int w_out, const int* hbounds, const int* hkk, int hksize,
+                            const int* vbounds, const int* vkk, int vksize, void* stream);
+
 /* ------------------------------------------------------------------ K3/K4/K5: convolution
  * Implicit-GEMM convolution on MFMA.  Replaces nn.Conv2d(+BatchNorm2d eval)(+ReLU)
  * (+residual add) of model/resnet_cubic.py:85-106,163-175, the per-face CAM GEMM of

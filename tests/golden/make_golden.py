@@ -241,13 +241,40 @@ def gen_clstm(R, out):
     print('clstm fixtures written')
 
 
+RESIZE_CASES = [((94, 188), (64, 128)), ((54, 96), (48, 96)), ((50, 100), (64, 128)), ((97, 131), (61, 203))]
+
+
+def resize_input(k):
+    (h, w), _ = RESIZE_CASES[k]
+    from cp_360_weakly_supervised_saliency_amd.utils import hashrng
+    return (hashrng.uniform(7000 + k, (h, w, 3), 0.0, 256.0)).astype(np.uint8)
+
+
+def gen_resize(out):
+    """dataset_feat_extractor.py:131-133 with the REAL Pillow of this image:
+    Image.fromarray(frame).convert('RGB').resize((w, h), resample=Image.LANCZOS)."""
+    import PIL
+    from PIL import Image
+    arrs = {'pillow_version': np.array(PIL.__version__)}
+    for k, (_, (oh, ow)) in enumerate(RESIZE_CASES):
+        a = resize_input(k)
+        arrs['y%d' % k] = np.array(Image.fromarray(a).convert('RGB').resize((ow, oh), resample=Image.LANCZOS))
+    np.savez_compressed(os.path.join(out, 'resize_lanczos.npz'), **arrs)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='cubepad,e2c,c2e,resnet,clstm')
+    ap.add_argument('--only', default='cubepad,e2c,c2e,resnet,clstm,resize')
     args = ap.parse_args()
+    parts = args.only.split(',')
+    if 'resize' in parts:                      # Pillow only: the reference itself is not needed
+        gen_resize(HERE)
+        parts.remove('resize')
+    if not parts:
+        return
     R = import_reference()
     R['torch'].set_num_threads(8)
-    for part in args.only.split(','):
+    for part in parts:
         {'cubepad': gen_cubepad, 'e2c': gen_e2c, 'c2e': gen_c2e,
          'resnet': gen_resnet, 'clstm': gen_clstm}[part](R, HERE)
 
