@@ -46,6 +46,7 @@ struct ConvK {
     int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
     int nt, mt, m_fast;
     int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
+    int epi_direct;                       // 1: direct 16-byte epilogue, 0: LDS-staged epilogue
 };
 
 template <typename T> struct Elem;
@@ -57,6 +58,14 @@ template <> struct Elem<f16_raw> { static constexpr int EPC = 8; };
 // load from here, so the select happens on the ADDRESS before the load and nothing has
 // to wait for the loaded data until the ds_write that consumes it.
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// Channel order inside a 32-row group of the packed weights.  MFMA row block i gives a lane the
+// four consecutive rows 4*(lane>>4) .. +3; the pack kernel permutes the rows so that blocks 2p
+// and 2p+1 TOGETHER give it EIGHT consecutive channels:  packed row 32q + 16*b + 4*g + e  holds
+// channel 32q + 8*g + 4*b + e.  A lane then owns a 16-byte (bf16) / 32-byte (f32) piece of a pixel
+// and the four lane groups of a pixel 64 / 128 contiguous bytes: outputs, residuals and split-K
+// slabs are moved with 16-byte accesses straight from / to global memory.
+__device__ __forceinline__ int acc_chan(int i, int lane) { return (i >> 1) * 32 + (lane >> 4) * 8 + (i & 1) * 4; }
 
 __device__ __forceinline__ int lds_swz(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -118,6 +127,114 @@ __device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+// ------------------------------------------------------------------ direct epilogue (16-byte pieces)
+// With the acc_chan row order a lane owns 8 consecutive channels of a pixel per block pair: bias,
+// residual, ReLU, ONE rounding and the store happen on 16-byte pieces straight against global memory
+// (a pixel's four lane groups cover 64 bytes (16-bit types) / 128 bytes (f32) contiguously) - no LDS
+// round trip, no barriers, and the residual loads of JB pixel blocks are in flight together.
+__device__ __forceinline__ u32x4 pack8(const float v[8], bf16_raw) {
+    u32x4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3],
+                      (f16_raw)v[4], (f16_raw)v[5], (f16_raw)v[6], (f16_raw)v[7]};
+    return __builtin_bit_cast(u32x4, h);
+}
+__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], bf16_raw) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = __builtin_bit_cast(f16x8v, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+}
+
+template <typename T, int MJ>
+__device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[4][MJ], int n0, int m0, int wch0, int wrow0,
+                                                int lane, int rows_valid) {
+    constexpr int JB = sizeof(T) == 4 ? 2 : 5;             // pixel blocks whose residual pieces are in flight together
+    const int ml = lane & 15;
+    const T* res = reinterpret_cast<const T*>(p.res);
+    T* outp = reinterpret_cast<T*>(p.out);
+    const int rlim = min(rows_valid, p.M - m0);            // tile rows that are output pixels
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const int n = n0 + wch0 + pr * 32 + (lane >> 4) * 8;
+        const bool nok = n < p.c_out;                      // c_out % 8 == 0 on this path
+        float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nok) {
+            const float4 t0 = *reinterpret_cast<const float4*>(p.bias + n);
+            const float4 t1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < MJ; j0 += JB) {
+            u32x4 rr[JB][sizeof(T) == 4 ? 2 : 1];
+            if (res) {
+#pragma unroll
+                for (int u = 0; u < JB; ++u) {
+                    const int row = wrow0 + (j0 + u) * 16 + ml;
+                    if (j0 + u < MJ) {
+                        const bool ok = nok && row < rlim;
+                        const T* src = ok ? res + (size_t)(m0 + row) * p.ld_res + n : reinterpret_cast<const T*>(g_zero16);
+                        rr[u][0] = *reinterpret_cast<const u32x4*>(src);
+                        if constexpr (sizeof(T) == 4) rr[u][1] = *reinterpret_cast<const u32x4*>(ok ? src + 4 : src);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const int j = j0 + u;
+                if (j >= MJ) continue;
+                const int row = wrow0 + j * 16 + ml;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * pr][j][e] + bb[e];
+                    v[4 + e] = acc[2 * pr + 1][j][e] + bb[4 + e];
+                }
+                if (res) {
+                    float r[8];
+                    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            r[e] = __uint_as_float(rr[u][0][e]);
+                            r[4 + e] = __uint_as_float(rr[u][1][e]);
+                        }
+                    } else {
+                        unpack8(rr[u][0], r, T());
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (nok && row < rlim) {
+                    T* dst = outp + (size_t)(m0 + row) * p.ld_out + p.out_coff + n;
+                    if constexpr (sizeof(T) == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        *reinterpret_cast<u32x4*>(dst) = pack8(v, T());
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ epilogue through LDS
 // A lane holds 4 consecutive channels of one pixel per MFMA tile: stored directly that is
 // 8-byte (bf16) pieces a pixel stride apart - fine for the f32 split-K slabs, wasteful for
@@ -140,7 +257,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
     constexpr int S = HC * (int)sizeof(T) + 16;            // LDS row stride (bytes), 16-byte aligned
     static_assert(BM * S <= LDS_BYTES, "epilogue tile does not fit the LDS of this kernel");
     constexpr int UB = MJ > 8 ? 4 : 8;                     // 16-byte accesses in flight per thread (register budget)
-    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const int ml = lane & 15;
     const T* res = reinterpret_cast<const T*>(p.res);
     T* outp = reinterpret_cast<T*>(p.out);
 #pragma unroll 1
@@ -174,9 +291,9 @@ __device__ __forceinline__ void epilogue_lds(const ConvK& p, unsigned char* lds,
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int cn = wch0 + i * 16;                      // tile channel of this MFMA row block
+            const int cn = wch0 + (i >> 1) * 32;               // 32-channel group of this MFMA row block
             if (cn / HC != h) continue;                        // wave-uniform
-            const int ncol = cn + nl - h * HC;                 // channel inside this half
+            const int ncol = wch0 + acc_chan(i, lane) - h * HC;   // channel inside this half
             const int n = nh0 + ncol;
             float bb[4] = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && n < p.c_out) {
@@ -402,10 +519,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
         return;
     }
     // ---- epilogue: lane holds channels n..n+3 of pixel m for every (i, j) sub-tile
-    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const int ml = lane & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + nl;
+        const int n = n0 + wn * 64 + acc_chan(i, lane);
         if (n >= p.c_out) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -622,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     }
 
     // ---- epilogue: through LDS (full-line accesses) unless it is a split-K slab or misaligned
-    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const int ml = lane & 15;
     const bool lds_epi = !p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
                          (p.ld_res % EPC == 0);
     if (lds_epi) {
@@ -632,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + nl;
+        const int n = n0 + wn * 64 + acc_chan(i, lane);
         if (n >= p.c_out) continue;
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -688,8 +805,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM> struct RingGeom {
-    static constexpr int BN = 256, NSTAGE = 4;
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n);   // s_waitcnt vmcnt(min(n, N)), n wave-uniform
+template <> __device__ __forceinline__ void wait_vmcnt_upto<0>(int) { wait_vmcnt<0>(); }
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    if (n >= N) wait_vmcnt<N>();
+    else wait_vmcnt_upto<N - 1>(n);
+}
+
+template <int BM, int NS = 4> struct RingGeom {
+    static constexpr int BN = 256, NSTAGE = NS;
     static constexpr int A_PASSES = BN / 128;                    // 128 tile rows per 512-thread pass
     static constexpr int B_FULL = BM / 128;                      // full activation passes
     static constexpr int B_REM = BM % 128;                       // rows of the partial pass (0 or 48)
@@ -708,11 +832,11 @@ template <int BM> struct RingGeom {
 // K loop + epilogue of one wave: channels [wch0, wch0+64) x MJ pixel blocks from tile row wrow0.
 // JH = pixel blocks of the first half of a sub-step (their activation fragments are held at once;
 // the other MJ - JH reuse the registers).  LAG: this wave runs half a sub-step behind (waves 4-7).
-template <typename T, int BM, int MJ, int JH, bool LAG>
+template <typename T, int BM, int MJ, int JH, bool LAG, int NS = 4>
 __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, const int n0, const int m0, const int split,
                                           const int wave, const int lane, const int tid, const int wch0,
                                           const int wrow0) {
-    typedef RingGeom<BM> G;
+    typedef RingGeom<BM, NS> G;
     constexpr int BN = G::BN, STAGE = G::STAGE, A_PASSES = G::A_PASSES, B_PASSES = G::B_PASSES;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BKS = 4 * EPC;                               // K elements per sub-step (64 bytes)
@@ -800,8 +924,9 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
         const int lrow = lane & 15, lchunk = lane >> 4;
         set_tap(tap);
         issue(0);
-        if (nloc > 1) { advance(); issue(1); }
-        if (nloc > 2) { advance(); issue(2); }
+#pragma unroll
+        for (int k = 1; k < NS - 1; ++k)
+            if (nloc > k) { advance(); issue(k); }
         int stage = 0;
         // A sub-step is two PHASES separated by a second barrier, and the two waves that share a
         // SIMD (w and w+4) run half a sub-step apart (MI355X_MICROARCH.md, "Two waves per SIMD",
@@ -834,7 +959,7 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
             unsigned sbase = 0;                                                                            \
             if (REFILL) {                                                                                  \
                 advance();                                                                                 \
-                sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)((stage + 3) & 3) * STAGE);    \
+                sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)(stage == 0 ? NS - 1 : stage - 1) * STAGE); \
             }                                                                                              \
             _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                               \
                 if (REFILL && j < D0) issue_one(j, sbase);                                                 \
@@ -842,8 +967,10 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
                 if (JH + j < MJ)   /* column j is done: its registers take pixel block JH + j */           \
                     b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + (JH + j) * 16 + lrow, lchunk)); \
             }                                                                                              \
+            _Pragma("unroll") for (int q = JH; q < D0; ++q)   /* more DMA passes than MFMA columns (BM = 128) */ \
+                if (REFILL) issue_one(q, sbase);                                                           \
             if (REFILL && G::XWAVES > 0 && xw) issue_one(D0, sbase);                                       \
-            stage = (stage + 1) & 3;                                                                       \
+            stage = stage == NS - 1 ? 0 : stage + 1;                                                       \
         }
 #define CP360_RING_TAIL()                                                                                  \
         {                                                                                                  \
@@ -862,14 +989,13 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
             if (!LAG) CP360_RING_TAIL() else CP360_RING_HEAD(REFILL)                                       \
         }
         int it = 0;
-        for (; it + 3 < nloc; ++it) {               // steady state: two younger DMA groups in flight
-            if (xw) wait_vmcnt<2 * D1>(); else wait_vmcnt<2 * D0>();
+        for (; it + NS - 1 < nloc; ++it) {          // steady state: NS-2 younger DMA groups in flight
+            if (xw) wait_vmcnt<(NS - 2) * D1>(); else wait_vmcnt<(NS - 2) * D0>();
             CP360_RING_STEP(true)
         }
         for (; it < nloc; ++it) {                   // drain: no refill
-            if (it + 2 < nloc)      { if (xw) wait_vmcnt<2 * D1>(); else wait_vmcnt<2 * D0>(); }
-            else if (it + 1 < nloc) { if (xw) wait_vmcnt<D1>(); else wait_vmcnt<D0>(); }
-            else                    wait_vmcnt<0>();
+            const int young = min(NS - 2, nloc - 1 - it);
+            wait_vmcnt_upto<(NS - 2) * D1>(young * (xw ? D1 : D0));
             CP360_RING_STEP(false)
         }
         if (LAG) CP360_RING_TAIL()
@@ -878,7 +1004,11 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
 #undef CP360_RING_TAIL
     }
 
-    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const int ml = lane & 15;
+    if (!p.partial && p.epi_direct) {
+        epilogue_direct<T, MJ>(p, acc, n0, m0, wch0, wrow0, lane, BM);
+        return;
+    }
     if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
         (p.ld_res % EPC == 0)) {
         epilogue_lds<T, BN, BM, MJ, 512, G::template lds_bytes<T>()>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid);
@@ -886,7 +1016,7 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wch0 + i * 16 + nl;
+        const int n = n0 + wch0 + acc_chan(i, lane);
         if (n >= p.c_out) continue;
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -952,6 +1082,41 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     }
 }
 
+// Short-K variant (the HBM-bound 1x1 convolutions of ResNet, K <= 512): 256 x 128 tile, two 24 KiB
+// stages, 64 accumulator registers per lane - two workgroups fit a CU (launch bounds 4 waves per
+// SIMD), so one tile's epilogue traffic overlaps the other's operand loads and MFMAs.  A single
+// 160 KiB-LDS workgroup per CU runs load, compute, residual and store phases strictly one after the
+// other (ablations in DESIGN.md).  Epilogue: direct 16-byte pieces (no LDS).
+template <typename T>
+__global__ __launch_bounds__(512, 4) void conv_igemm_ring2_kernel(const ConvK p) {
+    typedef RingGeom<128, 2> G;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::template lds_bytes<T>()];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int n0, m0, split;
+    {
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int nt_i, mt_i;
+        if (p.m_fast) {
+            mt_i = w % p.mt;
+            const int rest = w / p.mt;
+            nt_i = rest % p.nt;
+            split = rest / p.nt;
+        } else {
+            nt_i = w % p.nt;
+            const int rest = w / p.nt;
+            mt_i = rest % p.mt;
+            split = rest / p.mt;
+        }
+        n0 = nt_i * G::BN;
+        m0 = mt_i * 128;
+    }
+    if (wave < 4) ring_body<T, 128, 4, 2, false, 2>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 64);
+    else          ring_body<T, 128, 4, 2, true, 2>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 64);
+}
+
 // ------------------------------------------------------------------ clip-resident ConvLSTM convolution
 // CubePad(1) + 3x3 convolution on 7x7 cube faces (model/clstm.py:56-64 at the 224-pixel cube size).
 // CubePad only ever copies from the other faces of the SAME cube (cube_pad.py:114-216), so the nine
@@ -973,13 +1138,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
 // multiples of 16: 9.6e7 conflict cycles per launch measured with it, profiles/).
 // Tile / wave layout and the half-sub-step stagger are those of the 256x304 ring kernel.
 __device__ __forceinline__ int clip_swz(int row) { return ((row >> 2) & 1) << 1; }
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n);   // s_waitcnt vmcnt(min(n, N)), n wave-uniform
-template <> __device__ __forceinline__ void wait_vmcnt_upto<0>(int) { wait_vmcnt<0>(); }
-template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n) {
-    if (n >= N) wait_vmcnt<N>();
-    else wait_vmcnt_upto<N - 1>(n);
-}
 
 struct ClipGeom {
     static constexpr int BN = 256, BM = 304, NW = 6, NA = 2;
@@ -1165,7 +1323,7 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
 #undef CP360_CLIP_TAIL
     }
 
-    const int nl = (lane >> 4) * 4, ml = lane & 15;
+    const int ml = lane & 15;
     if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
         (p.ld_res % EPC == 0)) {
         epilogue_lds<T, BN, BM, MJ, 512, G::LDS_BYTES>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid, p.clip_rows);
@@ -1173,7 +1331,7 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wch0 + i * 16 + nl;
+        const int n = n0 + wch0 + acc_chan(i, lane);
         if (n >= p.c_out) continue;
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
@@ -1346,6 +1504,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
             tap = (int)(t % taps);
             n = (int)(t / taps);
         }
+        // n is the packed row; its channel (acc_chan): row 32q + 16b + 4g + e <- channel 32q + 8g + 4b + e
+        n = (n & ~31) + ((n >> 2) & 3) * 8 + ((n >> 4) & 1) * 4 + (n & 3);
         float v = 0.f;
         if (n < c_out) {
             if (stem_mode) {   // desc kh=7, kw=1, c_in=32: k = kx*4 + ch of a [c_out,3,7,7] filter
@@ -1383,8 +1543,10 @@ static int check_desc(const cp360_conv_desc* d) {
         d->sx <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_out <= 0 || d->splits < 1 || d->pix_stride <= 0)
         return CP360_ERR_BAD_SHAPE;
     const int epc = 16 / elem_bytes(d->dtype);
-    if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 256 && d->tile_px != 304)
+    if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 256 &&
+        d->tile_px != 304)
         return CP360_ERR_BAD_SHAPE;
+    if (d->tile_px == 129 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;   // 16-bit types only (128-VGPR budget)
     if (d->clip_resident != 0 && d->clip_resident != 1) return CP360_ERR_BAD_SHAPE;
     // clip-resident kernel: CubePad(1) + 3x3 stride 1 on faces whose cube (6 n^2 pixels) fits one 304-row tile
     if (d->clip_resident && !(d->pad_mode == 1 && d->pad == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 &&
@@ -1483,6 +1645,16 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
     }();
     const ConvPlan c = plan_candidate(d, 256, 304, 256, 2.2 * 304.0 / 256.0);   // 19 pixel blocks: 7x7 cube faces
     if (!no304 && c.cost < best.cost) best = c;
+    // short-K 1x1 convolutions (HBM-bound): 256x128 tile with two workgroups per CU (pixel tile id 129)
+    static const int ring2 = []() {
+        const char* e = getenv("CP360_RING2");             // A/B switch for tools/bench_conv.py
+        return e ? atoi(e) : 1;
+    }();
+    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && d->c_in * elem_bytes(d->dtype) <= 1024) {
+        ConvPlan r2 = plan_candidate(d, 256, 128, 512, 1.25);
+        r2.bm = 129;
+        if (r2.cost < best.cost) best = r2;
+    }
     return best;
 }
 
@@ -1576,6 +1748,15 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     k.clip_rows = 6 * d->h_out * d->w_out;
     k.nsub = k.k_total / (bk / 2);
     k.sub_per_split = (k.nsub + d->splits - 1) / d->splits;
+    // Epilogue of the ring kernels: LDS-staged full-line stores by default; the direct 16-byte-piece
+    // epilogue measured the same on the big tiles (within 1 %) and is what the two-workgroups-per-CU
+    // short-K kernel uses (no LDS left for a staged tile there).  CP360_EPI=1 selects it everywhere.
+    static const int epi_mode = []() {
+        const char* e = getenv("CP360_EPI");
+        return e ? atoi(e) : 0;
+    }();
+    const bool epi_ok = d->c_out % 8 == 0 && d->ld_out % 8 == 0 && d->out_coff % 8 == 0 && d->ld_res % 8 == 0;
+    k.epi_direct = (epi_mode && epi_ok) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (d->clip_resident) {
         k.nt = (k.c_out + 255) / 256;
@@ -1596,7 +1777,8 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
         // 256x256 tiles carry 1.5x the flops per byte brought into the CU; use them unless the
         // pixel count pads badly (small-M launches) - then 256x128
         const bool big = bm_ >= 256;
-        const int bm = bm_;
+        const int bm = bm_ == 129 ? 128 : bm_;
+        if (bm_ == 129 && epi_ok) k.epi_direct = 1;
         k.nt = (k.c_out + 255) / 256;
         k.mt = (k.M + bm - 1) / bm;
         k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
@@ -1612,7 +1794,9 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
             else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 8>), grid, dim3(512), 0, st, k);       \
             else          hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 4>), grid, dim3(512), 0, st, k);       \
         }
-        if (d->dtype == CP360_F32) CP360_WIDE(float)
+        if (bm_ == 129 && d->dtype == CP360_F16) hipLaunchKernelGGL((conv_igemm_ring2_kernel<f16_raw>), grid, dim3(512), 0, st, k);
+        else if (bm_ == 129) hipLaunchKernelGGL((conv_igemm_ring2_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+        else if (d->dtype == CP360_F32) CP360_WIDE(float)
         else if (d->dtype == CP360_F16) CP360_WIDE(f16_raw)
         else CP360_WIDE(bf16_raw)
 #undef CP360_WIDE

@@ -165,8 +165,9 @@ typedef struct {
     int splits;       /* split-K factor (>= 1); > 1 needs `partial`               */
     int tile_px;      /* 0: the library's launch planner picks the tile; for c_out >=
                          256 (tuning, tests): 128 / 256 / 304 force the pixel tile
-                         of the 8-wave 256-channel kernels, 64 forces the 4-wave
-                         128x128 kernel                                           */
+                         of the 8-wave 256-channel kernels (129 = the 256x128 short-K
+                         kernel that runs two workgroups per CU), 64 forces the
+                         4-wave 128x128 kernel                                    */
     int clip_resident;/* 1: CubePad(1) + 3x3 stride-1 convolution on cube faces small
                          enough that a whole cube (6 n^2 <= 304 pixels, n <= 7: the
                          ConvLSTM of model/clstm.py at cube size 224) is one tile:

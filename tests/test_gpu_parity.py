@@ -237,6 +237,35 @@ def test_wide_conv_forced_pixel_tiles(tile_px, prec, splits):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('cin', [64, 200])
+@pytest.mark.parametrize('use_res', [False, True])
+def test_short_k_two_workgroup_kernel(prec, cin, use_res):
+    """tile_px = 129: the 256x128 two-stage kernel that runs two workgroups per CU (1x1 convolutions with a
+    short K: layer1-3 conv3 / downsample), direct 16-byte epilogue.  M = 6*11*11 = 726 pixels (ragged last
+    tile), c_out = 520 (ragged channel tile, multiple of 8), K = 64 (two sub-steps = the two stages) and 200
+    (seven sub-steps, K tail)."""
+    dt = _TDT[prec]
+    n_img, cout, n = 6, 520, 11
+    x = hashrng.normal(9500 + cin, (n_img, cin, n, n))
+    w = hashrng.normal(9501, (cout, cin, 1, 1), 0, (2.0 / cin) ** 0.5)
+    scale = hashrng.uniform(9502, (cout,), 0.5, 1.5)
+    bias = hashrng.normal(9503, (cout,), 0, 0.1)
+    res = hashrng.normal(9504, (n_img, cout, n, n)) if use_res else None
+    rb = (lambda a: torch.from_numpy(a).to(dt).float().numpy()) if prec != 'fp32' else (lambda a: a)
+    w_ref = rb(w * scale[:, None, None, None]) if prec != 'fp32' else w * scale[:, None, None, None]
+    want = _conv_ref(rb(x), w_ref.astype(np.float32), None, bias, 1, 0, True, None if res is None else rb(res))
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 1, 0, True, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    rt = None if res is None else ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
+    if prec == 'fp32':          # 16-bit types only: the kernel lives inside a 128-VGPR budget
+        with pytest.raises(Exception):
+            conv(xt, residual=rt, tile_px=129)
+        return
+    got = ops.nhwc_to_nchw(conv(xt, residual=rt, tile_px=129), out_dtype=torch.float32).cpu().numpy()
+    assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
+
+
 @pytest.mark.parametrize('n', [7, 5, 3])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('splits', [1, 3, 7])
