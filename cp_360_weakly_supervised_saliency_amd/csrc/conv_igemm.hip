@@ -461,11 +461,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     const int nloc = s_end - s_begin;
     if (nloc > 0) {
         const int lrow = lane & 15, lchunk = lane >> 4;
+        // a K step whose second 64-byte half is all padding (the bf16 / fp16 stem: 32 of 64 elements
+        // per tap) skips that half's fragment reads and MFMAs
+        const bool half_k = p.steps_per_tap == 1 && 2 * p.c_in <= BK;
         auto compute = [&](int buf) __attribute__((always_inline)) {
             const unsigned char* As = lds + buf * STAGE;
             const unsigned char* Bs = As + BN * 128;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
+                if (kk == 1 && half_k) break;
                 u32x4 a[4], b[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)

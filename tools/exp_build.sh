@@ -18,6 +18,6 @@ cp $R/include/cp360.h $D/include/
 cd $D/pkg/csrc
 python3 $R/tools/exp_patch.py conv_igemm.hip "$V"
 sed -i 's#"../../include/cp360.h"#"'$D'/include/cp360.h"#' common.h
-for f in cubepad conv_igemm misc projection; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c $f.hip -o $f.o & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so cubepad.o conv_igemm.o misc.o projection.o
+for f in *.hip; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c $f -o ${f%.hip}.o & done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so *.o
 echo $D/libcp360.so
