@@ -105,6 +105,8 @@ def main():
     ap.add_argument('--cube', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--frame-chunk', type=int, default=0, help='frames per static-stage group (0 = all)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step from a HIP graph (launch-bound small configs; no per-kernel roofline timing)')
     ap.add_argument('--source', default='', help='decoded frame size HxW: include the PIL-exact Lanczos resize (K0) in the step')
     ap.add_argument('--static-only', action='store_true',
                     help='BASELINE config C2: the static path only (equi -> cube -> ResNet-50 -> CAM); no roofline object')
@@ -132,7 +134,10 @@ def main():
     n_clips = world * B
 
     timer = LaunchTimer()
-    ops.LAUNCH_TIMER = timer
+    if args.graph and not args.static_only:
+        eng.capture(frames)
+    else:
+        ops.LAUNCH_TIMER = timer
 
     def step():
         if args.static_only:

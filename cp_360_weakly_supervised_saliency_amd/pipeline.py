@@ -78,14 +78,39 @@ class SaliencyEngine:
     def temporal_stage(self, cam=None):
         return self.runner.run(self.cam if cam is None else cam)
 
+    # ---- hipGraph replay (launch-bound small configurations: one frame / one clip)
+    def capture(self, frames):
+        """Record the whole path over ``frames`` (u8/f32 [B, T, H, W, 3] on the device) into a HIP
+        graph.  Later ``__call__``s replay it: ~70 + 7*T kernel launches become one graph launch, which
+        is what bounds single-frame / single-clip latency (BASELINE configs C2, C3).  The graph reads the
+        captured tensor's memory: calls with another tensor copy into it first."""
+        with torch.no_grad():
+            self._graph = None
+            self._forward(frames)                       # warm-up: packs weights, sizes every buffer
+            torch.cuda.synchronize()
+            self._graph_in = frames
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_out = self._forward(self._graph_in)
+            self._graph = g
+        return self
+
+    def _forward(self, frames):
+        B, T = frames.shape[:2]
+        if (B, T) != (self.B, self.T):
+            raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
+        self.static_stage(frames.reshape((B * T,) + tuple(frames.shape[2:])))
+        return self.temporal_stage()
+
     def __call__(self, frames):
         """frames [B, T, H, W, 3] (u8 or f32, device) -> saliency f32 [B, 2w, 4w]."""
         with torch.no_grad():
-            B, T = frames.shape[:2]
-            if (B, T) != (self.B, self.T):
-                raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
-            self.static_stage(frames.reshape((B * T,) + tuple(frames.shape[2:])))
-            return self.temporal_stage()
+            if getattr(self, '_graph', None) is not None:
+                if frames.data_ptr() != self._graph_in.data_ptr():
+                    self._graph_in.copy_(frames)
+                self._graph.replay()
+                return self._graph_out
+            return self._forward(frames)
 
 
 def _to_tensors(sd):
