@@ -1,0 +1,224 @@
+// K3a: the ResNet stem, CubePad(3) -> conv 7x7 stride 2 (3 -> 64) + BN + ReLU
+// (model/resnet_cubic.py:115-128,163-168), as a resident-patch MFMA kernel for 16-bit types at the
+// reference's cube size (224: padded faces 230x230, output 112x112).
+//
+// The generic implicit GEMM treats the 7x7 filter as 7 taps of 8 pixels x 4 channels and re-gathers a
+// 64-byte im2col row per output pixel and tap: 4.2 GB through the L2 -> LDS path for 64 frames, which
+// is what bounds it (0.63 ms).  Here a workgroup owns a band of 8 output rows of one face:
+//   * the 21 padded input rows the band needs are ONE contiguous 38,640-byte range of the NHWC4 image
+//     and are copied to LDS once by LDS-DMA (double-buffered: the next band loads while this one runs);
+//   * the MFMA B fragment of (output pixel ox, filter row ky, k-chunk c) is the 16 bytes at
+//     row (2*oy + ky), byte 16*(ox + c) of that patch - pixels 2ox+2c, 2ox+2c+1 x 4 channels - so the
+//     fragments are read straight from the raw patch: no im2col copy exists anywhere;
+//   * the 64 x (7 x 32) weights (28 KiB) stay in LDS for the life of the workgroup (persistent grid).
+// Wave w computes output row w of the band: 112 pixels x 64 channels = 7 x 4 MFMA tiles, 7 k-steps.
+// Epilogue: bias + ReLU, one rounding, 16-byte pieces straight to global (acc_chan row order: a lane
+// holds 8 consecutive channels), 128 contiguous bytes per pixel.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+constexpr int CD = 224, WP = CD + 6, WO = CD / 2;            // padded input width, output width
+constexpr int ROW_BYTES = WP * 8;                            // 1840: one padded input row (4 x 16-bit per pixel)
+constexpr int BAND = 8, PATCH_ROWS = 2 * (BAND - 1) + 7;     // 21 input rows per band of 8 output rows
+constexpr int PATCH_BYTES = PATCH_ROWS * ROW_BYTES;          // 38,640
+constexpr int PATCH_LDS = 38 * 1024;                         // DMA granule: 38 x 1 KiB
+constexpr int W_BYTES = 7 * 64 * 64;                         // [ky][64 rows][32 k] 16-bit
+constexpr int MJ = WO / 16;                                  // 7 pixel blocks per output row
+
+__device__ __attribute__((aligned(16))) unsigned int s_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ int w_swz(int row, int chunk) {   // 64-byte weight rows: as the ring kernel's stages
+    return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
+}
+template <typename T> __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma<bf16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<f16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], bf16_raw) {
+    u32x4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3],
+                      (f16_raw)v[4], (f16_raw)v[5], (f16_raw)v[6], (f16_raw)v[7]};
+    return __builtin_bit_cast(u32x4, h);
+}
+}  // namespace
+
+// packed stem weights: [ky][row r][k] with row r <- channel acc_chan order (row 32q + 16b + 4g + e holds
+// channel 32q + 8g + 4b + e), k = kx*4 + ch (kx < 7, ch < 3; the rest zero), BN scale folded in f32
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                        T* __restrict__ packed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 7 * 64 * 32) return;
+    const int k = idx & 31, r = (idx >> 5) & 63, ky = idx >> 11;
+    const int n = (r & ~31) + ((r >> 2) & 3) * 8 + ((r >> 4) & 1) * 4 + (r & 3);
+    const int kx = k >> 2, ch = k & 3;
+    float v = 0.f;
+    if (kx < 7 && ch < 3) v = w[((n * 3 + ch) * 7 + ky) * 7 + kx] * (scale ? scale[n] : 1.f);
+    if constexpr (__is_same(T, f16_raw)) packed[idx] = (f16_raw)v;
+    else packed[idx] = f32_to_bf16(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, const T* __restrict__ wpk,
+                                                      const float* __restrict__ bias, T* __restrict__ out, int n_img,
+                                                      int relu) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[W_BYTES + 2 * PATCH_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int ntiles = n_img * (WO / BAND);
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xp);
+    const size_t img_bytes = (size_t)WP * ROW_BYTES;
+
+    // patch of tile t -> buffer b: 38 DMA instructions of 1 KiB, wave w issues w, w+8, ...; the bytes
+    // past the 38,640 of the patch come from a zero line (never read by the MFMAs)
+    auto load_patch = [&](int t, int b) __attribute__((always_inline)) {
+        const int img = t / (WO / BAND), band = t - img * (WO / BAND);
+        const unsigned char* src0 = xb + (size_t)img * img_bytes + (size_t)(2 * BAND * band) * ROW_BYTES;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int inst = wave + 8 * q;
+            if (inst < 38) {
+                const int off = inst * 1024 + lane * 16;
+                const void* src = off < PATCH_BYTES ? (const void*)(src0 + off) : (const void*)s_zero16;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_base + W_BYTES + b * PATCH_LDS + inst * 1024));
+            }
+        }
+    };
+    // weights: 28 KiB = 28 instructions, source-side swizzle (lane l lands in row l>>2, chunk l&3)
+    {
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int inst = wave + 8 * q;
+            if (inst < 28) {
+                const int row = inst * 16 + (lane >> 2);                  // 0..447 = ky*64 + r
+                const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
+                glds16(wb + row * 64 + chunk * 16, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+            }
+        }
+    }
+    int t = blockIdx.x;
+    if (t < ntiles) load_patch(t, 0);
+
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    float bb[2][8];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[pr][e] = bias ? bias[pr * 32 + (lane >> 4) * 8 + e] : 0.f;
+
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the patch (and weights) landed
+        __syncthreads();                                           // everyone's did; the other buffer is free
+        if (t + (int)gridDim.x < ntiles) load_patch(t + gridDim.x, buf ^ 1);
+
+        f32x4 acc[4][MJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* P = lds + W_BYTES + buf * PATCH_LDS + (2 * wave) * ROW_BYTES + 16 * (lrow + lchunk);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            u32x4 a[4], b[MJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(lds + w_swz(ky * 64 + i * 16 + lrow, lchunk));
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) b[j] = *reinterpret_cast<const u32x4*>(P + ky * ROW_BYTES + j * 256);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) mma<T>(acc[i][j], a[i], b[j]);
+        }
+        // epilogue: output row (band*8 + wave) of image img
+        const int img = t / (WO / BAND), band = t - img * (WO / BAND);
+        T* orow = out + ((size_t)img * WO + band * BAND + wave) * WO * 64;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n = pr * 32 + (lane >> 4) * 8;
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * pr][j][e] + bb[pr][e];
+                    v[4 + e] = acc[2 * pr + 1][j][e] + bb[pr][4 + e];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *reinterpret_cast<u32x4*>(orow + (size_t)(j * 16 + lrow) * 64 + n) = pack8(v, T());
+            }
+        }
+    }
+}
+
+extern "C" size_t cp360_stem_packed_bytes(int dtype) {
+    return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)W_BYTES : 0;
+}
+
+extern "C" int cp360_stem_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
+    if (!w_oihw || !packed) return CP360_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CP360_BF16)
+        hipLaunchKernelGGL((stem_pack_kernel<bf16_raw>), dim3(56), dim3(256), 0, st, w_oihw, scale, (bf16_raw*)packed);
+    else if (dtype == CP360_F16)
+        hipLaunchKernelGGL((stem_pack_kernel<f16_raw>), dim3(56), dim3(256), 0, st, w_oihw, scale, (f16_raw*)packed);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_stem_forward(int dtype, const void* xp, const void* packed, const float* bias, void* out, int n_img,
+                                  int cube_dim, int relu, void* stream) {
+    if (!xp || !packed || !out) return CP360_ERR_NULL;
+    if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
+    if (cube_dim != CD) return CP360_ERR_UNSUPPORTED;           // other cube sizes: the generic implicit GEMM
+    if ((long long)n_img * WP * ROW_BYTES >= (1LL << 40)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = n_img * (WO / BAND);
+    const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
+    if (dtype == CP360_BF16)
+        hipLaunchKernelGGL((stem_kernel<bf16_raw>), grid, dim3(512), 0, st, (const bf16_raw*)xp, (const bf16_raw*)packed,
+                           bias, (bf16_raw*)out, n_img, relu);
+    else if (dtype == CP360_F16)
+        hipLaunchKernelGGL((stem_kernel<f16_raw>), grid, dim3(512), 0, st, (const f16_raw*)xp, (const f16_raw*)packed,
+                           bias, (f16_raw*)out, n_img, relu);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

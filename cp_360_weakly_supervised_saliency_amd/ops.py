@@ -186,6 +186,7 @@ class Conv:
                              and self.c_out >= 256)
         self.clip_resident_ok = bool(clip_resident)
         self._packed = {}
+        self._stem_packed = None                # resident-patch stem kernel (16-bit types, cube 224), on first use
         self._partial = None
         self._splits_cache = {}
 
@@ -232,6 +233,21 @@ class Conv:
         d.clip_resident = clip_resident
         return d
 
+    def _stem_resident(self, xp):
+        """cp360_stem_forward: the padded faces' rows of an 8-row output band stay in LDS (K3a)."""
+        L = lib()
+        code = dtype_code(self.dtype)
+        if self._stem_packed is None:
+            w = self._w_src.to(device=self.device, dtype=torch.float32).contiguous()
+            t = torch.empty(L.cp360_stem_packed_bytes(code), dtype=torch.uint8, device=self.device)
+            check(L.cp360_stem_pack_weights(code, ptr(w), ptr(self._scale), ptr(t), stream()))
+            self._stem_packed = t
+        n_img = xp.shape[0]
+        out = torch.empty((n_img, 112, 112, 64), dtype=self.dtype, device=xp.device)
+        check(L.cp360_stem_forward(code, ptr(xp.contiguous()), ptr(self._stem_packed), ptr(self.bias), ptr(out), n_img,
+                                   224, int(self.relu), stream()))
+        return out
+
     def nsteps(self):
         bk = 32 if self.dtype == torch.float32 else 64
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
@@ -244,6 +260,10 @@ class Conv:
         reduction / bias / activation the caller finishes (cp360_lstm_gates, CAM)."""
         require_gpu(x, residual, out)
         n_img, h_in, w_in, cx = x.shape
+        if (self.stem and h_in == 230 and w_in == 230 and cx == 4 and residual is None and out is None and not raw_f32
+                and splits is None and tile_px == 0 and self.dtype in (torch.bfloat16, torch.float16)
+                and x.dtype == self.dtype):
+            return self._stem_resident(x)
         if x.dtype != self.dtype:
             raise ValueError("activation dtype %s != conv dtype %s" % (x.dtype, self.dtype))
         if not self.stem and cx != self.c_in:

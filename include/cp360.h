@@ -200,6 +200,20 @@ int cp360_conv_forward(const cp360_conv_desc* d, const void* in, const void* pac
 int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const float* bias,
                       const void* residual, void* out, void* stream);
 
+/* ------------------------------------------------------------------ K3a: resident-patch stem
+ * conv 7x7 stride 2 (3 -> 64) + folded BatchNorm + ReLU of model/resnet_cubic.py:115-128,163-168 on the
+ * materialised CubePad(3) input [n_img, cd+6, cd+6, 4] (NHWC4, 16-bit) -> [n_img, cd/2, cd/2, 64], for
+ * cube_dim 224 and CP360_BF16 / CP360_F16 (other sizes / f32: CP360_ERR_UNSUPPORTED - use the generic
+ * convolution in its "7 taps of 8 pixels x 4 channels" form).  Same arithmetic as the generic path
+ * (16-bit products, f32 accumulate, one rounding); the input rows a band of output rows needs are
+ * copied to LDS once and the MFMA fragments are read from the raw rows (no im2col anywhere).
+ */
+size_t cp360_stem_packed_bytes(int dtype);
+int cp360_stem_pack_weights(int dtype, const float* w_oihw /* [64,3,7,7] */, const float* scale /* [64] or NULL */,
+                            void* packed, void* stream);
+int cp360_stem_forward(int dtype, const void* xp, const void* packed, const float* bias, void* out,
+                       int n_img, int cube_dim, int relu, void* stream);
+
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),
  * NHWC, pad fused: x [n6, n, n, C] -> y [n6, (n-1)/2+... , .., C] with

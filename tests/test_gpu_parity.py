@@ -321,6 +321,35 @@ def test_stem_conv_and_maxpool(prec):
     assert np.array_equal(pooled, want_pool)     # max of identical values: exact
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_stem_resident_patch_kernel_cube224(prec):
+    """K3a at the reference's cube size: CubePad(3) -> 7x7 s2 conv + BN + ReLU on 12 faces of 224x224
+    (two cubes: several bands per workgroup are not needed for parity, the persistent loop is exercised by
+    168 tiles on <= 256 workgroups... so also run 60 faces to make workgroups loop) against torch-CPU on the
+    same rounded operands, and against the generic implicit GEMM (summation order only)."""
+    dt = _TDT[prec]
+    for n_img, seed in ((12, 9600), (60, 9610)):
+        x = hashrng.normal(seed, (n_img, 3, 224, 224))
+        w = hashrng.normal(9601, (64, 3, 7, 7), 0, (2.0 / (49 * 64)) ** 0.5)
+        scale = hashrng.uniform(9602, (64,), 0.5, 1.5)
+        bias = hashrng.normal(9603, (64,), 0, 0.1)
+        conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 2, 0, True, dt, DEV, stem=True)
+        x3 = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV))
+        x4 = ops.cubepad_nhwc(x3, 0, c_out=4)
+        x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)
+        xp = ops.cubepad_nhwc(x4, 3)                                   # [n_img, 230, 230, 4]
+        got = conv(xp)                                                 # resident-patch kernel
+        assert got.shape == (n_img, 112, 112, 64)
+        gen = conv(xp, tile_px=0, splits=1)                            # splits given -> generic path
+        g, e = got.float().cpu().numpy(), gen.float().cpu().numpy()
+        assert rel_err(g, e) <= _TOL[prec], rel_err(g, e)
+        if n_img == 12:
+            rb = lambda a: torch.from_numpy(a).to(dt).float().numpy()
+            w_ref = rb(w * scale[:, None, None, None])
+            want = _conv_ref(rb(x), w_ref, None, bias, 2, 3, True)
+            assert rel_err(ops.nhwc_to_nchw(got, out_dtype=torch.float32).cpu().numpy(), want) <= _TOL[prec]
+
+
 # ------------------------------------------------------------------ ResNet-50-cubic + CAM
 def _load_resnet(prec='fp32'):
     sd = synth.resnet50_state(seed=1)
