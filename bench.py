@@ -179,8 +179,8 @@ def main():
             tp = os.path.join(REPO, 'profiles', 'traffic_%s.json' % args.precision)
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get('conv_igemm_clstm_bytes_per_launch')
-            roof = {'bound': 'mfma', 'kernel': 'conv_clip_kernel (ConvLSTM Conv2/Gates, M=%d N=4000 K=36000)'
-                    % (6 * B * eng.w * eng.w), 'achieved': round(ach, 2), 'peak': PEAK[args.precision],
+            roof = {'bound': 'mfma', 'kernel': '%s (ConvLSTM Conv2/Gates, M=%d N=4000 K=36000)'
+                    % ('conv_clip_kernel' if eng.w <= 7 else 'conv_igemm_ring_kernel', 6 * B * eng.w * eng.w), 'achieved': round(ach, 2), 'peak': PEAK[args.precision],
                     'unit': 'TFLOP/s', 'frac': round(ach / PEAK[args.precision], 4), 'traffic': traffic,
                     'avg_launch_ms': round(ms, 4), 'launches_timed': n, 'flops_per_launch': flops}
         line = {

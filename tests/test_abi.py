@@ -81,3 +81,17 @@ def test_ops_refuse_cpu_tensors():
     import torch
     with pytest.raises(RuntimeError):
         ops.cubepad_nchw(torch.zeros(6, 1, 4, 4), 1)
+
+
+def test_stem_and_resize_entry_points_validate_without_gpu():
+    """Argument validation happens before any launch: error codes on the CPU box."""
+    import ctypes as C
+    L = _lib.lib()
+    assert L.cp360_stem_packed_bytes(_lib.BF16) == 7 * 64 * 64 and L.cp360_stem_packed_bytes(_lib.F32) == 0
+    one = C.c_void_p(16)
+    assert L.cp360_stem_forward(_lib.BF16, None, one, None, one, 6, 224, 1, None) == -5          # NULL
+    assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 6, 512, 1, None) == -8           # other cube sizes
+    assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 0, 224, 1, None) == -1           # bad shape
+    assert L.cp360_resize_ksize(3840, 1920) == 13 and L.cp360_resize_ksize(100, 200) == 7
+    assert L.cp360_resize_ksize(0, 5) == -1
+    assert L.cp360_resize_lanczos_u8(None, one, None, 1, 4, 4, 2, 2, None, None, 0, None, None, 0, None) == -5
