@@ -1654,7 +1654,9 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
         const char* e = getenv("CP360_RING2");             // A/B switch for tools/bench_conv.py
         return e ? atoi(e) : 1;
     }();
-    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && d->c_in * elem_bytes(d->dtype) <= 1024) {
+    // (K of at least two 128-byte steps: at K = 64 elements the one-workgroup 256x304 tile measured faster)
+    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && d->c_in * elem_bytes(d->dtype) >= 256 &&
+        d->c_in * elem_bytes(d->dtype) <= 1024) {
         ConvPlan r2 = plan_candidate(d, 256, 128, 512, 1.25);
         r2.bm = 129;
         if (r2.cost < best.cost) best = r2;
