@@ -33,7 +33,7 @@ SYMBOLS = [
     'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits',
     'cp360_conv_pack_weights', 'cp360_conv_forward', 'cp360_conv_finish',
     'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_window_minmax',
-    'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward',
+    'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes', 'cp360_band3x3_pack_weights', 'cp360_band3x3_forward',
 ]
 
 
@@ -92,6 +92,10 @@ def lib():
     L.cp360_stem_packed_bytes.argtypes = [i]
     L.cp360_stem_pack_weights.argtypes = [i, vp, vp, vp, vp]
     L.cp360_stem_forward.argtypes = [i, vp, vp, vp, vp, i, i, i, vp]
+    L.cp360_band3x3_packed_bytes.restype = sz
+    L.cp360_band3x3_packed_bytes.argtypes = [i]
+    L.cp360_band3x3_pack_weights.argtypes = [i, vp, vp, vp, vp]
+    L.cp360_band3x3_forward.argtypes = [i, vp, vp, vp, vp, i, i, i, i, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     _lib = L

@@ -187,6 +187,7 @@ class Conv:
         self.clip_resident_ok = bool(clip_resident)
         self._packed = {}
         self._stem_packed = None                # resident-patch stem kernel (16-bit types, cube 224), on first use
+        self._band_packed = None                # resident-band 3x3 kernel (64 -> 64 on 56x56 faces), on first use
         self._partial = None
         self._splits_cache = {}
 
@@ -248,6 +249,20 @@ class Conv:
                                    224, int(self.relu), stream()))
         return out
 
+    def _band_resident(self, x):
+        """cp360_band3x3_forward: layer1 conv2 with the band's padded pixels resident in LDS (K3c)."""
+        L = lib()
+        code = dtype_code(self.dtype)
+        if self._band_packed is None:
+            w = self._w_src.to(device=self.device, dtype=torch.float32).contiguous()
+            t = torch.empty(L.cp360_band3x3_packed_bytes(code), dtype=torch.uint8, device=self.device)
+            check(L.cp360_band3x3_pack_weights(code, ptr(w), ptr(self._scale), ptr(t), stream()))
+            self._band_packed = t
+        out = torch.empty_like(x)
+        check(L.cp360_band3x3_forward(code, ptr(x.contiguous()), ptr(self._band_packed), ptr(self.bias), ptr(out),
+                                      x.shape[0], 56, 64, int(self.relu), stream()))
+        return out
+
     def nsteps(self):
         bk = 32 if self.dtype == torch.float32 else 64
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
@@ -264,6 +279,11 @@ class Conv:
                 and splits is None and tile_px == 0 and self.dtype in (torch.bfloat16, torch.float16)
                 and x.dtype == self.dtype):
             return self._stem_resident(x)
+        if (not self.stem and self.c_in == 64 and self.c_out == 64 and self.kh == 3 and self.kw == 3 and self.pad == 1
+                and self.stride == 1 and h_in == 56 and w_in == 56 and n_img % 6 == 0 and residual is None and out is None
+                and not raw_f32 and splits is None and tile_px == 0 and self.dtype in (torch.bfloat16, torch.float16)
+                and x.dtype == self.dtype):
+            return self._band_resident(x)
         if x.dtype != self.dtype:
             raise ValueError("activation dtype %s != conv dtype %s" % (x.dtype, self.dtype))
         if not self.stem and cx != self.c_in:

@@ -214,6 +214,19 @@ int cp360_stem_pack_weights(int dtype, const float* w_oihw /* [64,3,7,7] */, con
 int cp360_stem_forward(int dtype, const void* xp, const void* packed, const float* bias, void* out,
                        int n_img, int cube_dim, int relu, void* stream);
 
+/* ------------------------------------------------------------------ K3c: resident-band 3x3
+ * CubePad(1) + conv 3x3 stride 1 (64 -> 64) + folded BatchNorm + ReLU = conv2 / bn2 / relu of layer1's
+ * Bottlenecks (model/resnet_cubic.py:85-106) at cube size 224 (56x56 faces), CP360_BF16 / CP360_F16.
+ * x [n_img, 56, 56, 64] NHWC -> out [n_img, 56, 56, 64].  Other shapes / f32: CP360_ERR_UNSUPPORTED
+ * (cp360_conv_forward handles them).  A band of 4 output rows' padded pixels is gathered to LDS once
+ * (through the CubePad map) and all nine taps read it there.
+ */
+size_t cp360_band3x3_packed_bytes(int dtype);
+int cp360_band3x3_pack_weights(int dtype, const float* w_oihw /* [64,64,3,3] */, const float* scale /* or NULL */,
+                               void* packed, void* stream);
+int cp360_band3x3_forward(int dtype, const void* x, const void* packed, const float* bias, void* out,
+                          int n_img, int face, int channels, int relu, void* stream);
+
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),
  * NHWC, pad fused: x [n6, n, n, C] -> y [n6, (n-1)/2+... , .., C] with

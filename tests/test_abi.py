@@ -92,6 +92,9 @@ def test_stem_and_resize_entry_points_validate_without_gpu():
     assert L.cp360_stem_forward(_lib.BF16, None, one, None, one, 6, 224, 1, None) == -5          # NULL
     assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 6, 512, 1, None) == -8           # other cube sizes
     assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 0, 224, 1, None) == -1           # bad shape
+    assert L.cp360_band3x3_packed_bytes(_lib.F16) == 9 * 64 * 128
+    assert L.cp360_band3x3_forward(_lib.BF16, one, one, None, one, 6, 28, 128, 1, None) == -8     # other shapes
+    assert L.cp360_band3x3_forward(_lib.BF16, one, one, None, one, 7, 56, 64, 1, None) == -2      # not 6N
     assert L.cp360_resize_ksize(3840, 1920) == 13 and L.cp360_resize_ksize(100, 200) == 7
     assert L.cp360_resize_ksize(0, 5) == -1
     assert L.cp360_resize_lanczos_u8(None, one, None, 1, 4, 4, 2, 2, None, None, 0, None, None, 0, None) == -5

@@ -350,6 +350,29 @@ def test_stem_resident_patch_kernel_cube224(prec):
             assert rel_err(ops.nhwc_to_nchw(got, out_dtype=torch.float32).cpu().numpy(), want) <= _TOL[prec]
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_band3x3_resident_kernel_layer1_conv2(prec):
+    """K3c: CubePad(1) + 3x3 conv 64 -> 64 + BN + ReLU on 56x56 faces (12 faces = two cubes: the halo of
+    every band comes through cubepad_src from the other faces of ITS cube) against torch-CPU on the same
+    rounded operands and against the generic implicit GEMM."""
+    dt = _TDT[prec]
+    n_img = 12
+    x = hashrng.normal(9700, (n_img, 64, 56, 56))
+    w = hashrng.normal(9701, (64, 64, 3, 3), 0, (2.0 / (9 * 64)) ** 0.5)
+    scale = hashrng.uniform(9702, (64,), 0.5, 1.5)
+    bias = hashrng.normal(9703, (64,), 0, 0.1)
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 1, 1, True, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    got = conv(xt)                                                     # resident-band kernel
+    gen = conv(xt, splits=1)                                           # splits given -> generic path
+    assert got.shape == gen.shape == (n_img, 56, 56, 64)
+    g, e = got.float().cpu().numpy(), gen.float().cpu().numpy()
+    assert rel_err(g, e) <= _TOL[prec], rel_err(g, e)
+    rb = lambda a: torch.from_numpy(a).to(dt).float().numpy()
+    want = _conv_ref(rb(x), rb(w * scale[:, None, None, None]), None, bias, 1, 1, True)
+    assert rel_err(ops.nhwc_to_nchw(got, out_dtype=torch.float32).cpu().numpy(), want) <= _TOL[prec]
+
+
 # ------------------------------------------------------------------ ResNet-50-cubic + CAM
 def _load_resnet(prec='fp32'):
     sd = synth.resnet50_state(seed=1)
