@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         'dtype', 'n_img', 'h_in', 'w_in', 'c_in', 'pix_stride', 'kh', 'kw', 'sy', 'sx',
         'h_out', 'w_out', 'c_out', 'pad_mode', 'pad', 'ld_out', 'out_coff', 'ld_res',
-        'relu', 'splits', 'tile_px', 'clip_resident')]
+        'relu', 'splits', 'tile_px', 'clip_resident', 'slab_rows')]
 
 
 class Cp360Error(RuntimeError):
@@ -82,7 +82,7 @@ def lib():
     L.cp360_conv_forward.argtypes = [pd, vp, vp, vp, vp, vp, vp, vp]
     L.cp360_conv_finish.argtypes = [pd, vp, vp, vp, vp, vp]
     L.cp360_cubepad_maxpool3s2.argtypes = [vp, vp, i, i, i, i, vp]
-    L.cp360_lstm_gates.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, vp]
+    L.cp360_lstm_gates.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, i, vp]
     L.cp360_window_minmax.argtypes = [vp, vp, vp, i, sz, sz, vp]
     L.cp360_window_normalize.argtypes = [vp, vp, vp, i, i, i, vp, i, i, i, i, i, sz, vp]
     L.cp360_resize_ksize.argtypes = [i, i]

@@ -47,6 +47,7 @@ struct ConvK {
     int nt, mt, m_fast;
     int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
     int epi_direct;                       // 1: direct 16-byte epilogue, 0: LDS-staged epilogue
+    int slab_rows;                        // 1: split-K slabs in packed-row column order (slab_col)
 };
 
 template <typename T> struct Elem;
@@ -66,6 +67,11 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // and the four lane groups of a pixel 64 / 128 contiguous bytes: outputs, residuals and split-K
 // slabs are moved with 16-byte accesses straight from / to global memory.
 __device__ __forceinline__ int acc_chan(int i, int lane) { return (i >> 1) * 32 + (lane >> 4) * 8 + (i & 1) * 4; }
+// Split-K slabs (cp360_conv_desc.slab_rows) keep the PACKED row order inside each 32-channel group, so the
+// four lane groups of a pixel store 64 contiguous bytes per MFMA block (in true channel order a store
+// instruction would write 16-byte pieces 32 bytes apart: +37 % HBM write traffic measured).  Column of the
+// 4-channel group that starts at channel n (n % 4 == 0):
+__host__ __device__ __forceinline__ int slab_col(int n) { return (n & ~31) + ((n >> 3) & 3) * 4 + ((n >> 2) & 1) * 16; }
 
 __device__ __forceinline__ int lds_swz(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
             if (m >= p.M) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
-                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);
             } else {
                 if (p.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
             if (m >= p.M) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
-                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);
             } else {
                 if (p.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
@@ -1028,7 +1034,7 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
             if (m >= p.M) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
-                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);
             } else {
                 if (p.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
@@ -1344,7 +1350,7 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
             const int m = m0 + row;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
-                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + n, v);
+                store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);
             } else {
                 if (p.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
@@ -1411,15 +1417,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ partial, int splits,
                                                           const float* __restrict__ bias, const T* __restrict__ res,
                                                           int ld_res, T* __restrict__ out, int ld_out, int out_coff,
-                                                          int M, int c_out, int relu) {
+                                                          int M, int c_out, int relu, int slab_rows) {
     const int q = c_out >> 2;
     const long long total = (long long)M * q;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / q), n = (int)(idx - (long long)m * q) * 4;
+        const int nc = slab_rows ? slab_col(n) : n;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < splits; ++s) {
-            const float4 t = *reinterpret_cast<const float4*>(partial + ((size_t)s * M + m) * c_out + n);
+            const float4 t = *reinterpret_cast<const float4*>(partial + ((size_t)s * M + m) * c_out + nc);
             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
         }
         if (bias) {
@@ -1447,7 +1454,7 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ c_prev, float* __restrict__ c_next,
                                                          T* __restrict__ h_out, int ld_h, int h_coff,
-                                                         float* __restrict__ h_f32, int M, int Hc) {
+                                                         float* __restrict__ h_f32, int M, int Hc, int slab_rows) {
     const int q = Hc >> 2, G = 4 * Hc;
     const long long total = (long long)M * q;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1460,10 +1467,11 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
             g[k][0] = bb.x; g[k][1] = bb.y; g[k][2] = bb.z; g[k][3] = bb.w;
         }
         for (int s = 0; s < splits; ++s) {
-            const float* base = gp + ((size_t)s * M + m) * G + j;
+            const float* base = gp + ((size_t)s * M + m) * G;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float4 t = *reinterpret_cast<const float4*>(base + k * Hc);
+                const int c = k * Hc + j;
+                const float4 t = *reinterpret_cast<const float4*>(base + (slab_rows ? slab_col(c) : c));
                 g[k][0] += t.x; g[k][1] += t.y; g[k][2] += t.z; g[k][3] += t.w;
             }
         }
@@ -1551,6 +1559,8 @@ static int check_desc(const cp360_conv_desc* d) {
         d->tile_px != 304)
         return CP360_ERR_BAD_SHAPE;
     if (d->tile_px == 129 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;   // 16-bit types only (128-VGPR budget)
+    if (d->slab_rows != 0 && d->slab_rows != 1) return CP360_ERR_BAD_SHAPE;
+    if (d->slab_rows && d->c_out % 32 != 0) return CP360_ERR_ALIGN;
     if (d->clip_resident != 0 && d->clip_resident != 1) return CP360_ERR_BAD_SHAPE;
     // clip-resident kernel: CubePad(1) + 3x3 stride 1 on faces whose cube (6 n^2 pixels) fits one 304-row tile
     if (d->clip_resident && !(d->pad_mode == 1 && d->pad == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 &&
@@ -1751,6 +1761,7 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     k.nsteps = d->kh * d->kw * k.steps_per_tap;
     k.steps_per_split = (k.nsteps + d->splits - 1) / d->splits;
     k.k_total = d->kh * d->kw * k.c_pad;
+    k.slab_rows = d->slab_rows;
     k.clip_rows = 6 * d->h_out * d->w_out;
     k.nsub = k.k_total / (bk / 2);
     k.sub_per_split = (k.nsub + d->splits - 1) / d->splits;
@@ -1833,38 +1844,39 @@ extern "C" int cp360_conv_finish(const cp360_conv_desc* d, const float* partial,
     if (d->dtype == CP360_F32)
         hipLaunchKernelGGL((conv_finish_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, partial, d->splits,
                            bias, (const float*)residual, d->ld_res, (float*)out, d->ld_out, d->out_coff, M, d->c_out,
-                           d->relu);
+                           d->relu, d->slab_rows);
     else if (d->dtype == CP360_F16)
         hipLaunchKernelGGL((conv_finish_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
                            d->splits, bias, (const f16_raw*)residual, d->ld_res, (f16_raw*)out, d->ld_out,
-                           d->out_coff, M, d->c_out, d->relu);
+                           d->out_coff, M, d->c_out, d->relu, d->slab_rows);
     else
         hipLaunchKernelGGL((conv_finish_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
                            d->splits, bias, (const bf16_raw*)residual, d->ld_res, (bf16_raw*)out, d->ld_out,
-                           d->out_coff, M, d->c_out, d->relu);
+                           d->out_coff, M, d->c_out, d->relu, d->slab_rows);
     CP360_CHECK_HIP();
     return CP360_OK;
 }
 
 extern "C" int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias, const float* c_prev,
                                 float* c_next, void* h_out, int h_dtype, int ld_h, int h_coff, float* h_f32, int M,
-                                int Hc, void* stream) {
+                                int Hc, int slab_rows, void* stream) {
     if (!gates_partial || !bias || !c_prev || !c_next || !h_out) return CP360_ERR_NULL;
     if (splits < 1 || M <= 0 || Hc <= 0) return CP360_ERR_BAD_SHAPE;
     if (Hc % 4 != 0 || ld_h % 4 != 0 || h_coff % 4 != 0) return CP360_ERR_ALIGN;
+    if (slab_rows && (4 * Hc) % 32 != 0) return CP360_ERR_ALIGN;
     const long long total = (long long)M * (Hc / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipStream_t st = (hipStream_t)stream;
     if (h_dtype == CP360_F32)
         hipLaunchKernelGGL((lstm_gates_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial, splits,
-                           bias, c_prev, c_next, (float*)h_out, ld_h, h_coff, h_f32, M, Hc);
+                           bias, c_prev, c_next, (float*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows);
     else if (h_dtype == CP360_BF16)
         hipLaunchKernelGGL((lstm_gates_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
-                           splits, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc);
+                           splits, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows);
     else if (h_dtype == CP360_F16)
         hipLaunchKernelGGL((lstm_gates_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
-                           splits, bias, c_prev, c_next, (f16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc);
+                           splits, bias, c_prev, c_next, (f16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

@@ -85,9 +85,10 @@ class ConvLSTMCell(nn.Module):
         n6, w, _, _ = xh.shape
         a1 = p['c1'](xh, out=None if bufs is None else bufs[0])
         a2 = p['c2'](a1, out=None if bufs is None else bufs[1])
-        partial, splits = p['g'](a2, raw_f32=True)
+        sr = (4 * self.hidden_size) % 32 == 0              # gate slabs in packed-row order (64-byte stores)
+        partial, splits = p['g'](a2, raw_f32=True, slab_rows=sr)
         ops.lstm_gates(partial, splits, p['gbias'], c_prev, c_next, xh, self.input_size, h_f32,
-                       n6 * w * w, self.hidden_size)
+                       n6 * w * w, self.hidden_size, slab_rows=sr)
 
     def forward(self, input_, prev_state=None):
         """input_ [6B, Cin, w, w]; prev_state = (hidden, cell) [6B, Ch, w, w] or None

@@ -217,7 +217,7 @@ class Conv:
                ((w_in + p2 - self.kw_w) // self.stride + 1 if self.stem else (w_in + p2 - self.kw) // self.stride + 1)
 
     def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None, tile_px=0,
-              clip_resident=0):
+              clip_resident=0, slab_rows=0):
         d = ConvDesc()
         d.dtype = dtype_code(self.dtype)
         d.n_img, d.h_in, d.w_in = n_img, h_in, w_in
@@ -232,6 +232,7 @@ class Conv:
         d.splits = splits
         d.tile_px = tile_px
         d.clip_resident = clip_resident
+        d.slab_rows = slab_rows
         return d
 
     def _stem_resident(self, xp):
@@ -268,7 +269,7 @@ class Conv:
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
 
     def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None,
-                 tile_px=0, clip_resident=None):
+                 tile_px=0, clip_resident=None, slab_rows=False):
         """x [n_img, h, w, c] NHWC (for the stem: the materialised CubePad(3) output
         [n_img, h+6, w+6, 4]).  Returns [n_img, h_out, w_out, c_out] in self.dtype, or
         with raw_f32=True the (partial [splits, M, c_out] f32, splits) pair whose
@@ -306,7 +307,13 @@ class Conv:
             if splits is None:
                 splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1, clip_resident=cr)))
                 self._splits_cache[key] = splits
-        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res, tile_px=tile_px, clip_resident=cr)
+        # split-K slabs read back by cp360_conv_finish (or, on request, by cp360_lstm_gates) keep the packed
+        # row order: contiguous 64-byte stores (cp360_conv_desc.slab_rows)
+        sr = int(self.c_out % 32 == 0 and ((splits > 1 and not raw_f32) or (raw_f32 and slab_rows)))
+        if raw_f32 and slab_rows and not sr:
+            raise ValueError("slab_rows needs c_out % 32 == 0")
+        d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res, tile_px=tile_px, clip_resident=cr,
+                       slab_rows=sr)
         packed = self.packed_for(cr)
         def forward(*a):
             if LAUNCH_TIMER is None:
@@ -350,9 +357,10 @@ def cubepad_maxpool3s2(x):
     return y
 
 
-def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, Hc):
+def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, Hc, slab_rows=False):
     check(lib().cp360_lstm_gates(ptr(partial), splits, ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out),
-                                 dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc, stream()))
+                                 dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc,
+                                 int(slab_rows), stream()))
 
 
 def window_minmax(x, B, per_clip, minmax, scratch, clip_stride=0):

@@ -175,6 +175,12 @@ typedef struct {
                          every tap reads the clip's activations from an LDS-resident
                          tile (cubepad halo never leaves the cube).  Must be the same
                          at pack and forward time; other geometries: UNSUPPORTED    */
+    int slab_rows;    /* 1: the f32 `partial` sums keep the packed row order inside each
+                         32-channel group (the 4-channel group of channel n sits at
+                         column (n & ~31) + ((n >> 3) & 3) * 4 + ((n >> 2) & 1) * 16), so
+                         a pixel's lanes store 64 contiguous bytes; cp360_conv_finish
+                         (same desc) and cp360_lstm_gates(slab_rows = 1) read that order.
+                         Needs c_out % 32 == 0.  0: true channel order (raw CAM scores) */
 } cp360_conv_desc;
 
 /* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */
@@ -240,7 +246,7 @@ int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, int C, int d
  * h_out[m*ld_h + h_coff + j]; h_f32 (optional) receives an f32 copy [M, Hc]. */
 int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias,
                      const float* c_prev, float* c_next, void* h_out, int h_dtype,
-                     int ld_h, int h_coff, float* h_f32, int M, int Hc, void* stream);
+                     int ld_h, int h_coff, float* h_f32, int M, int Hc, int slab_rows, void* stream);
 
 /* ------------------------------------------------------------------ K7: window normalise
  * temporal_model/test_temporal.py:66-67,70-73,77: per clip min / max over the whole
