@@ -74,11 +74,15 @@ class LaunchTimer:
         return by
 
 
-def cpu_baseline(H, W, cd, precision_note):
+def cpu_baseline(H, W, cd, precision, dev):
     """The oracle (numpy / torch-CPU restatement of the reference, oracle/) on the host
     cores for a bounded sample: ONE clip of 2 frames at the benchmark resolution through
-    the whole path (static stage x2, ConvLSTM x2, cube->equi)."""
+    the whole path (static stage x2, ConvLSTM x2, cube->equi).  The same sample then goes
+    through the HIP path at the benchmark precision and the oracle acts as the checker for
+    the second half of the metric (AUC-Judd / CC of both maps against a synthetic fixation
+    map): reported under "check"."""
     from tests.parity_helpers import oracle_pipeline
+    from oracle import o_metrics
     # 32 threads: fastest setting measured on the GPU box's host (tools/cpu_threads_probe.py); using all
     # 256 hardware threads of the EPYC host makes oneDNN ~100x slower on these small convolutions
     torch.set_num_threads(min(32, os.cpu_count() or 1))
@@ -86,11 +90,19 @@ def cpu_baseline(H, W, cd, precision_note):
     cs = synth.clstm_state(seed=2)
     clip = synth.clip_u8(3, 2, H, W)
     t0 = time.time()
-    oracle_pipeline(clip, rs, cs, cd)
+    ref = oracle_pipeline(clip, rs, cs, cd)
     dt = time.time() - t0
+    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=2, precision=precision, device=dev)
+    got = eng(torch.from_numpy(clip[None]).to(dev)).float().cpu().numpy()[0]
+    fix = synth.fixation_map(103, H // 2, W // 2)
+    rng = lambda: np.random.RandomState(0)
+    check = {'max_abs_diff': float(np.max(np.abs(got - ref))),
+             'auc_judd': [round(o_metrics.auc_judd(ref, fix, rng=rng()), 6), round(o_metrics.auc_judd(got, fix, rng=rng()), 6)],
+             'cc': [round(o_metrics.corr_coeff(ref, fix), 6), round(o_metrics.corr_coeff(got, fix), 6)],
+             'what': 'oracle vs HIP (%s) saliency of the sample clip; [oracle, hip] metrics vs a synthetic fixation map' % precision}
     return {'value': round(2.0 / dt, 4), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': '1 clip x 2 frames %dx%d -> 6x%d^2, oracle fp32 (torch-CPU conv, numpy remap), %.1f s'
-                      % (H, W, cd, dt)}
+                      % (H, W, cd, dt), 'check': check}
 
 
 def main():
@@ -201,7 +213,7 @@ def main():
             'cpu_baseline': None,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(H, W, args.cube, args.precision)
+            line['cpu_baseline'] = cpu_baseline(H, W, args.cube, args.precision, dev)
         print(json.dumps(line))
     cpdist.barrier()
     if torch.distributed.is_initialized():
