@@ -47,6 +47,47 @@ __global__ __launch_bounds__(256) void cubepad_maxpool_kernel(const T* __restric
     }
 }
 
+// 16-bit types with C % 8 == 0: a thread owns 8 channels = one 16-byte piece (half the index
+// arithmetic of the 4-channel form per byte moved, 16-byte loads / stores).
+typedef __attribute__((ext_vector_type(4))) unsigned int mp_u32x4;
+template <typename T>
+__global__ __launch_bounds__(256) void cubepad_maxpool16_kernel(const T* __restrict__ x, T* __restrict__ y, int n6, int n,
+                                                                int C, int ho) {
+    const CubePadGeom g{n, 1, 1, 1, 1};
+    const int cv = C / 8;
+    const long long total = (long long)n6 * ho * ho * cv;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * 8;
+        long long t = idx / cv;
+        const int ox = (int)(t % ho);
+        t /= ho;
+        const int oy = (int)(t % ho);
+        const int img = (int)(t / ho);
+        const int grp = img / 6, f = img - grp * 6;
+        mp_u32x4 v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int s = cubepad_src(f, oy * 2 + k / 3, ox * 2 + k % 3, g);
+            v[k] = *reinterpret_cast<const mp_u32x4*>(x + ((size_t)grp * 6 * n * n + s) * C + c);
+        }
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const T* pv = reinterpret_cast<const T*>(&v[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], ld_f32<T>(pv + e));
+        }
+        mp_u32x4 o;
+        T* po = reinterpret_cast<T*>(&o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_f32<T>(po + e, m[e]);      // max of representable values: exact
+        *reinterpret_cast<mp_u32x4*>(y + (size_t)(t * ho + ox) * C + c) = o;
+    }
+}
+
 extern "C" int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, int C, int dtype, void* stream) {
     if (!x || !y) return CP360_ERR_NULL;
     if (n6 <= 0 || n < 2 || C <= 0) return CP360_ERR_BAD_SHAPE;
@@ -60,6 +101,12 @@ extern "C" int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, i
     if (dtype == CP360_F32)
         hipLaunchKernelGGL((cubepad_maxpool_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const float*)x, (float*)y, n6, n, C, ho);
+    else if (dtype == CP360_BF16 && C % 8 == 0)
+        hipLaunchKernelGGL((cubepad_maxpool16_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const bf16_raw*)x, (bf16_raw*)y, n6, n, C, ho);
+    else if (dtype == CP360_F16 && C % 8 == 0)
+        hipLaunchKernelGGL((cubepad_maxpool16_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st,
+                           (const f16_raw*)x, (f16_raw*)y, n6, n, C, ho);
     else if (dtype == CP360_BF16)
         hipLaunchKernelGGL((cubepad_maxpool_kernel<bf16_raw, 4>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const bf16_raw*)x, (bf16_raw*)y, n6, n, C, ho);

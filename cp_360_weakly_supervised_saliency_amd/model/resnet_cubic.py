@@ -171,16 +171,17 @@ class ResNet(nn.Module):
             self._cam_stamp = stamp
         return self._cam
 
-    def stem_nhwc(self, x_nhwc4):
+    def stem_nhwc(self, x_nhwc4, padded=False):
         """x [6N, H, W, 4] (normalised cube faces, 4th channel 0) -> [6N, H/4, W/4, 64]:
-        CubePad(3) -> conv7x7 s2 + BN + ReLU -> CubePad(1) + maxpool (resnet_cubic.py:165-170)."""
-        xp = ops.cubepad_nhwc(x_nhwc4, 3)
+        CubePad(3) -> conv7x7 s2 + BN + ReLU -> CubePad(1) + maxpool (resnet_cubic.py:165-170).
+        padded=True: x is already the CubePad(3) output [6N, H+6, W+6, 4] (Equi2Cube layout 'nhwc4p3')."""
+        xp = x_nhwc4 if padded else ops.cubepad_nhwc(x_nhwc4, 3)
         x = self._stem_conv()(xp)
         return ops.cubepad_maxpool3s2(x)
 
-    def features_nhwc(self, x_nhwc4):
+    def features_nhwc(self, x_nhwc4, padded=False):
         """Fused path to layer4: [6N, H, W, 4] -> [6N, H/32, W/32, 2048]."""
-        x = self.stem_nhwc(x_nhwc4)
+        x = self.stem_nhwc(x_nhwc4, padded)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk.forward_nhwc(x)

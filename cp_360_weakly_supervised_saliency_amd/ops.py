@@ -108,7 +108,9 @@ def nchw_view(x_nhwc):
 def equi2cube(frames, grid, cube_dim, out_dtype=torch.float32, layout='nhwc4', scale=None,
               mean=IMAGENET_MEAN, std=IMAGENET_STD, cv_fixed_point=True):
     """frames [F, H, W, 3] u8 / f32 (device), grid [6, cd, cd, 2] f32 (device).
-    Returns [6F, 3, cd, cd] (layout 'nchw') or [6F, cd, cd, 4] (layout 'nhwc4')."""
+    Returns [6F, 3, cd, cd] (layout 'nchw') or [6F, cd, cd, 4] (layout 'nhwc4').  ``grid`` may be any
+    [6, n, n, 2] table of sampling points with n = cube_dim: passing the CubePad(3)-gathered grid
+    ([6, cd+6, cd+6, 2], ``Equi2Cube.grid_p3``) with cube_dim = cd+6 yields the padded faces directly."""
     require_gpu(frames, grid)
     F, H, W, three = frames.shape
     if three != 3:
@@ -116,12 +118,13 @@ def equi2cube(frames, grid, cube_dim, out_dtype=torch.float32, layout='nhwc4', s
     frames = frames.contiguous()
     if scale is None:
         scale = 1.0 / 255.0 if frames.dtype == torch.uint8 else 1.0
-    shape = (6 * F, 3, cube_dim, cube_dim) if layout == 'nchw' else (6 * F, cube_dim, cube_dim, 4)
+    code = {'nchw': 0, 'nhwc4': 1}[layout]
+    shape = (6 * F, 3, cube_dim, cube_dim) if code == 0 else (6 * F, cube_dim, cube_dim, 4)
     out = torch.empty(shape, dtype=out_dtype, device=frames.device)
     m = (C.c_float * 3)(*[float(v) for v in mean])
     s = (C.c_float * 3)(*[float(np.float32(1.0) / np.float32(v)) for v in std])
     check(lib().cp360_equi2cube(ptr(frames), ptr(grid), ptr(out), F, H, W, cube_dim, m, s, float(scale),
-                                dtype_code(frames.dtype), dtype_code(out_dtype), 0 if layout == 'nchw' else 1,
+                                dtype_code(frames.dtype), dtype_code(out_dtype), code,
                                 1 if cv_fixed_point else 0, stream()))
     return out
 

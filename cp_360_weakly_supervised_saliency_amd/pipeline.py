@@ -71,8 +71,9 @@ class SaliencyEngine:
             chunk = frames[lo:hi]
             if self.resize is not None:
                 chunk = self.resize(chunk)
-            x4 = self.e2c.to_cube_batch(chunk, out_dtype=self.dtype, layout='nhwc4')
-            cam_device(x4, self.resnet, out=cam_flat[lo:hi])      # CAM conv writes the clip buffer directly
+            # K1 writes the CubePad(3)-padded faces directly (one pass instead of project + pad)
+            x4 = self.e2c.to_cube_batch(chunk, out_dtype=self.dtype, layout='nhwc4p3')
+            cam_device(x4, self.resnet, out=cam_flat[lo:hi], padded=True)     # CAM conv writes the clip buffer directly
         return self.cam
 
     def temporal_stage(self, cam=None):

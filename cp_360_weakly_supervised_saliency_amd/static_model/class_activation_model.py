@@ -12,11 +12,11 @@ import torch
 from .. import _lib, ops
 
 
-def cam_device(input_cubemap_nhwc4, model, out=None):
+def cam_device(input_cubemap_nhwc4, model, out=None, padded=False):
     """Fused device path: normalised cube faces [6N, H, W, 4] (NHWC4, the output of
     ``Equi2Cube.to_cube_batch``) -> (cube_score f32 [6N, h, w, 1000] NHWC,
     layer4 features [6N, h, w, 2048] NHWC in the model's compute dtype)."""
-    feat = model.features_nhwc(input_cubemap_nhwc4)
+    feat = model.features_nhwc(input_cubemap_nhwc4, padded)      # padded: the faces already carry their CubePad(3) ring
     cam = model.cam_conv()
     n6, h, w, _ = feat.shape
     # splits = 1 + raw f32 output: the CAM has no bias / activation, and its scores feed

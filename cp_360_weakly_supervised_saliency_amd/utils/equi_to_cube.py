@@ -85,12 +85,24 @@ class Equi2Cube:
         self.device = torch.device(device)
         self.cv_fixed_point = bool(cv_fixed_point)
         self._grid_dev = None
+        self._grid_p3_dev = None
 
     @property
     def grid(self):
         if self._grid_dev is None:
             self._grid_dev = torch.from_numpy(self.grid_host).to(self.device)
         return self._grid_dev
+
+    @property
+    def grid_p3(self):
+        """[6, cd+6, cd+6, 2]: the sampling grid gathered through CubePad(3) (the library's host table,
+        model/cube_pad.py:95-216).  A padded pixel is a copy of a cube pixel, so sampling it at that
+        pixel's grid point gives the CubePad(3) output of resnet_cubic.py:165 without a second pass."""
+        if self._grid_p3_dev is None:
+            tab = ops.cubepad_table(self.output_width, 3)                     # [6, cd+6, cd+6] flat source index
+            g = self.grid_host.reshape(-1, 2)[tab.reshape(-1)].reshape(tab.shape + (2,))
+            self._grid_p3_dev = torch.from_numpy(np.ascontiguousarray(g)).to(self.device)
+        return self._grid_p3_dev
 
     def to_cube(self, in_image):
         """[H, W, C=3] float array -> {0..5: [cd, cd, 3]} like the reference (:112-129):
@@ -107,7 +119,13 @@ class Equi2Cube:
     def to_cube_batch(self, frames, out_dtype=torch.float32, layout='nhwc4', normalize=True):
         """Device path: frames [F, H, W, 3] u8 / f32 tensor on the GPU -> the
         normalised network input of dataset_feat_extractor.py:142-157 in one kernel
-        ([6F, cd, cd, 4] NHWC4 or [6F, 3, cd, cd] NCHW)."""
+        ([6F, cd, cd, 4] NHWC4, [6F, 3, cd, cd] NCHW, or with layout 'nhwc4p3' the CubePad(3)-padded
+        NHWC4 faces [6F, cd+6, cd+6, 4] the stem reads)."""
+        if layout == 'nhwc4p3':
+            if not normalize:
+                raise ValueError("the padded layout is the network input: normalised only")
+            return ops.equi2cube(frames, self.grid_p3, self.output_width + 6, out_dtype, 'nhwc4',
+                                 cv_fixed_point=self.cv_fixed_point)
         if normalize:
             return ops.equi2cube(frames, self.grid, self.output_width, out_dtype, layout,
                                  cv_fixed_point=self.cv_fixed_point)

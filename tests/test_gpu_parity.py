@@ -505,6 +505,26 @@ def test_clstm_bf16_window(golden_dir, full_cell_state):
     assert np.max(err) <= 2e-2, np.max(err)       # bf16 moves the map by ~1e-3
 
 
+def test_e2c_padded_layout_equals_project_then_cubepad():
+    """Equi2Cube layout 'nhwc4p3' (CubePad(3) fused into K1) == K1 followed by the CubePad kernel, bit for
+    bit, for u8 / f32 inputs and every output type; and the fused max-pool's 16-byte path == the 4-channel
+    path on the same data."""
+    H, W, cd = 256, 512, 64
+    e = Equi2Cube(cd, (H, W))
+    fr = torch.from_numpy(np.stack([synth.frame_u8(70 + i, H, W) for i in range(3)])).to(DEV)
+    for frames in (fr, fr.float() / 255.0):
+        for dt in (torch.float32, torch.bfloat16, torch.float16):
+            a = e.to_cube_batch(frames, out_dtype=dt, layout='nhwc4p3')
+            b = ops.cubepad_nhwc(e.to_cube_batch(frames, out_dtype=dt, layout='nhwc4'), 3)
+            assert a.shape == (18, cd + 6, cd + 6, 4) and torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    x = torch.from_numpy(hashrng.normal(72, (6, 10, 10, 64))).to(DEV)
+    for dt in (torch.bfloat16, torch.float16):
+        xh = x.to(dt)
+        full = ops.cubepad_maxpool3s2(xh)                                            # C % 8 == 0: 16-byte path
+        part = torch.cat([ops.cubepad_maxpool3s2(xh[..., :60].contiguous()), ops.cubepad_maxpool3s2(xh[..., 60:].contiguous())], -1)
+        assert torch.equal(full, part)
+
+
 def test_window_minmax_and_normalize():
     B, T, P, C = 3, 4, 294, 1000
     x = hashrng.normal(83, (B, T, P, C), 5.0, 100.0)
