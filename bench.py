@@ -108,8 +108,8 @@ def cpu_baseline(H, W, cd, precision, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--precision', default=os.environ.get('CP360_PRECISION', 'bf16'), choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--clips', type=int, default=4, help='clips per GPU')
     ap.add_argument('--frames', type=int, default=16, help='frames per clip')
