@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Source patches for tools/exp_build.sh (timing experiments on the ring kernel; see there)."""
+"""Source patches for tools/exp_build.sh (timing experiments on the convolution kernels; see there).
+The patches are textual: a variant asserts if the code it rewrites has changed since it was written
+(`base` always builds)."""
 import sys
 
 path, variants = sys.argv[1], sys.argv[2].split('+')
