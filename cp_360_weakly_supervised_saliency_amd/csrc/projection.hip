@@ -21,17 +21,24 @@ template <> __device__ __forceinline__ float out_cvt<float>(float v) { return v;
 template <> __device__ __forceinline__ bf16_raw out_cvt<bf16_raw>(float v) { return f32_to_bf16(v); }
 template <> __device__ __forceinline__ f16_raw out_cvt<f16_raw>(float v) { return (f16_raw)v; }
 
+// A thread owns one output pixel g of FU consecutive frames: the grid point, the fixed-point split and
+// the bilinear weights are computed once, and the 2 x FU row loads of the frames are in flight together
+// (the one-pixel-one-frame form spent its time in two dependent round trips per output: grid, then taps).
 template <typename TI, typename TO, int LAYOUT, bool FIXED>
 __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ equi, const float2* __restrict__ grid,
                                                         TO* __restrict__ out, int F, int H, int W, int cd,
                                                         float m0, float m1, float m2, float s0, float s1, float s2,
                                                         float scale) {
+    constexpr int FU = 4;
     const long long per_frame = 6LL * cd * cd;
-    const long long total = (long long)F * per_frame;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int fr = (int)(idx / per_frame);
-        const int g = (int)(idx - (long long)fr * per_frame);          // face*cd*cd + i*cd + j
+    const int nfc = (F + FU - 1) / FU;
+    const long long total = per_frame * nfc;
+    const size_t frame_elems = (size_t)H * W * 3;
+    for (long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x; wi < total;
+         wi += (long long)gridDim.x * blockDim.x) {
+        const int fc = (int)(wi / per_frame);
+        const int g = (int)(wi - (long long)fc * per_frame);          // face*cd*cd + i*cd + j
+        const int fr0 = fc * FU;
         const float2 xy = grid[g];
         int ix, iy;
         float fx, fy;
@@ -48,53 +55,74 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
         const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
         const bool x0ok = ix >= 0 && ix < W, x1ok = ix + 1 >= 0 && ix + 1 < W;
         const bool y0ok = iy >= 0 && iy < H, y1ok = iy + 1 >= 0 && iy + 1 < H;
-        const TI* base = equi + (size_t)fr * H * W * 3;
-        float v[3];
+        auto emit = [&](int fr, float v[3]) {
+            v[0] = (v[0] - m0) * s0;
+            v[1] = (v[1] - m1) * s1;
+            v[2] = (v[2] - m2) * s2;
+            if (LAYOUT == 0) {   // [6F, 3, cd, cd]
+                const int face = g / (cd * cd), pix = g - face * cd * cd;
+                const size_t o = ((size_t)(fr * 6 + face) * 3) * cd * cd + pix;
+                out[o] = out_cvt<TO>(v[0]);
+                out[o + (size_t)cd * cd] = out_cvt<TO>(v[1]);
+                out[o + 2 * (size_t)cd * cd] = out_cvt<TO>(v[2]);
+            } else {             // [6F, cd, cd, 4]
+                const size_t o = ((size_t)fr * per_frame + g) * 4;
+                if constexpr (sizeof(TO) == 4) {
+                    *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], 0.f);
+                } else {
+                    typedef __attribute__((ext_vector_type(4))) TO vec4;
+                    const vec4 ov = {out_cvt<TO>(v[0]), out_cvt<TO>(v[1]), out_cvt<TO>(v[2]), out_cvt<TO>(0.f)};
+                    *reinterpret_cast<vec4*>(out + o) = ov;
+                }
+            }
+        };
         if (sizeof(TI) == 1 && ix >= 0 && iy >= 0 && ix + 4 < W && iy + 1 < H) {
             // u8 fast path: the two taps of a row are 6 adjacent bytes (HWC).  Instead of six byte
             // loads per row: one 12-byte load from the enclosing 4-byte-aligned address and a funnel
             // shift (ix + 4 < W keeps the 12 bytes inside the row).
-            auto row6 = [&](size_t byte_off) {
-                const size_t addr = (size_t)reinterpret_cast<const unsigned char*>(base) + byte_off;
-                const uint3 d = *reinterpret_cast<const uint3*>(addr & ~(size_t)3);
-                const unsigned sh = (unsigned)(addr & 3) * 8;
+            const size_t a0 = ((size_t)iy * W + ix) * 3;
+            uint3 d0[FU], d1[FU];
+            unsigned sh0[FU], sh1[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int fr = min(fr0 + u, F - 1);                 // frames past F re-read the last one (not stored)
+                const size_t ad0 = (size_t)reinterpret_cast<const unsigned char*>(equi) + (size_t)fr * frame_elems + a0;
+                const size_t ad1 = ad0 + (size_t)W * 3;
+                d0[u] = *reinterpret_cast<const uint3*>(ad0 & ~(size_t)3);
+                d1[u] = *reinterpret_cast<const uint3*>(ad1 & ~(size_t)3);
+                sh0[u] = (unsigned)(ad0 & 3) * 8;
+                sh1[u] = (unsigned)(ad1 & 3) * 8;
+            }
+            auto funnel = [](const uint3& d, unsigned sh) {
                 const unsigned long long lo = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
                 return sh ? (lo >> sh) | ((unsigned long long)d.z << (64 - sh)) : lo;
             };
-            const size_t a0 = ((size_t)iy * W + ix) * 3;
-            const unsigned long long q0 = row6(a0), q1 = row6(a0 + (size_t)W * 3);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float t00 = (float)((q0 >> (8 * c)) & 0xff), t01 = (float)((q0 >> (8 * (c + 3))) & 0xff);
-                const float t10 = (float)((q1 >> (8 * c)) & 0xff), t11 = (float)((q1 >> (8 * (c + 3))) & 0xff);
-                v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+            for (int u = 0; u < FU; ++u) {
+                if (fr0 + u >= F) break;
+                const unsigned long long q0 = funnel(d0[u], sh0[u]), q1 = funnel(d1[u], sh1[u]);
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float t00 = (float)((q0 >> (8 * c)) & 0xff), t01 = (float)((q0 >> (8 * (c + 3))) & 0xff);
+                    const float t10 = (float)((q1 >> (8 * c)) & 0xff), t11 = (float)((q1 >> (8 * (c + 3))) & 0xff);
+                    v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+                }
+                emit(fr0 + u, v);
             }
         } else {
+            for (int u = 0; u < FU && fr0 + u < F; ++u) {
+                const TI* base = equi + (size_t)(fr0 + u) * frame_elems;
+                float v[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float t00 = (x0ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix) * 3 + c) : 0.f;
-                const float t01 = (x1ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix + 1) * 3 + c) : 0.f;
-                const float t10 = (x0ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix) * 3 + c) : 0.f;
-                const float t11 = (x1ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix + 1) * 3 + c) : 0.f;
-                v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
-            }
-        }
-        v[0] = (v[0] - m0) * s0;
-        v[1] = (v[1] - m1) * s1;
-        v[2] = (v[2] - m2) * s2;
-        if (LAYOUT == 0) {   // [6F, 3, cd, cd]
-            const int face = g / (cd * cd), pix = g - face * cd * cd;
-            const size_t o = ((size_t)(fr * 6 + face) * 3) * cd * cd + pix;
-            out[o] = out_cvt<TO>(v[0]);
-            out[o + (size_t)cd * cd] = out_cvt<TO>(v[1]);
-            out[o + 2 * (size_t)cd * cd] = out_cvt<TO>(v[2]);
-        } else {             // [6F, cd, cd, 4]
-            if constexpr (sizeof(TO) == 4) {
-                *reinterpret_cast<float4*>(out + (size_t)idx * 4) = make_float4(v[0], v[1], v[2], 0.f);
-            } else {
-                typedef __attribute__((ext_vector_type(4))) TO vec4;
-                const vec4 o = {out_cvt<TO>(v[0]), out_cvt<TO>(v[1]), out_cvt<TO>(v[2]), out_cvt<TO>(0.f)};
-                *reinterpret_cast<vec4*>(out + (size_t)idx * 4) = o;
+                for (int c = 0; c < 3; ++c) {
+                    const float t00 = (x0ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix) * 3 + c) : 0.f;
+                    const float t01 = (x1ok && y0ok) ? px_load<TI>(base + ((size_t)iy * W + ix + 1) * 3 + c) : 0.f;
+                    const float t10 = (x0ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix) * 3 + c) : 0.f;
+                    const float t11 = (x1ok && y1ok) ? px_load<TI>(base + ((size_t)(iy + 1) * W + ix + 1) * 3 + c) : 0.f;
+                    v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
+                }
+                emit(fr0 + u, v);
             }
         }
     }
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
 template <typename TI, typename TO>
 static int launch_e2c(const void* equi, const float* grid, void* out, int F, int H, int W, int cd, const float* mean,
                       const float* istd, float scale, int layout, int fixed, hipStream_t st) {
-    const long long total = (long long)F * 6 * cd * cd;
+    const long long total = (long long)((F + 3) / 4) * 6 * cd * cd;      // one thread per pixel and group of 4 frames
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
 #define E2C_LAUNCH(L, FX)                                                                                       \
