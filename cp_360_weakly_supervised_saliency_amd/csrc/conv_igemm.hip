@@ -1149,28 +1149,35 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ring2_kernel(const ConvK p)
 // Tile / wave layout and the half-sub-step stagger are those of the 256x304 ring kernel.
 __device__ __forceinline__ int clip_swz(int row) { return ((row >> 2) & 1) << 1; }
 
-struct ClipGeom {
-    static constexpr int BN = 256, BM = 304, NW = 6, NA = 2;
+// FACE variant (16x16 faces, the ConvLSTM at cube size 512 - BASELINE config C5): a tile is ONE face (256
+// pixels, 8 + 8 pixel blocks) and the resident tile is that face WITH its CubePad(1) ring, 18 x 18 = 324
+// rows gathered through cubepad_src() at DMA time; a tap then reads row (y + ky) * 18 + x + kx.
+template <bool FACE> struct ClipGeom {
+    static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;
+    static constexpr int RROWS = FACE ? 336 : 304;               // resident rows (324 used in the FACE variant)
+    static constexpr int GROUP_ROWS = FACE ? 128 : 160;          // tile rows of wave group 0 (waves 0-3)
+    static constexpr int XW = (RROWS - 256) / 16;                // waves that carry the resident rows past 256
     static constexpr int WSTAGE = BN * 64;                       // 16 KiB of weights per sub-step
-    static constexpr int ATILE = BM * 64;                        // 19 KiB: one channel block of the clip
+    static constexpr int ATILE = RROWS * 64;                     // 19 / 21 KiB: one channel block of the clip / face
     static constexpr int TAB_ROW = 32;                           // bytes per (tap, wave group, lane row): 10 u16 + pad
     static constexpr int TAB_BYTES = 9 * 2 * 16 * TAB_ROW;
     static constexpr int OFF_ACT = NW * WSTAGE;
     static constexpr int OFF_TAB = OFF_ACT + NA * ATILE;
-    static constexpr int LDS_BYTES = OFF_TAB + TAB_BYTES;        // 146,432 B
+    static constexpr int LDS_BYTES = OFF_TAB + TAB_BYTES;        // 146,432 B (150,528 B FACE)
 };
 
-template <typename T, int MJ, int JH, bool LAG>
+template <typename T, int MJ, int JH, bool LAG, bool FACE>
 __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, const int n0, const int clip, const int split,
                                           const int wave, const int lane, const int tid, const int wch0, const int grp) {
-    typedef ClipGeom G;
+    typedef ClipGeom<FACE> G;
     constexpr int BN = G::BN, BM = G::BM;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BKS = 4 * EPC;                               // K elements per sub-step (64 bytes)
     constexpr int TAPS = 9;
-    const int wrow0 = grp * 160;
-    const bool xw = wave < 3;                                  // waves 0-2 carry the 48 rows past 256 of an activation tile
-    const int m0 = clip * p.clip_rows;
+    const int wrow0 = grp * G::GROUP_ROWS;
+    const bool xw = wave < G::XW;                              // the waves that carry the resident rows past 256
+    const int rows_valid = FACE ? 256 : p.clip_rows;           // tile rows that are output pixels
+    const int m0 = clip * rows_valid;                          // `clip` = cube (clip mode) or face image (FACE)
 
     // DMA role (as in the ring kernel): 16 rows x 4 chunks per wave-instruction, source-side swizzle
     const int drow = 16 * wave + (lane >> 2);
@@ -1181,11 +1188,21 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     const size_t wpass = (size_t)128 * p.k_total;
     const unsigned lds_base = (unsigned)(size_t)lds;
     const unsigned lds_wave = lds_base + (unsigned)(16 * wave) * 64;
-    int aoff[3];                                               // element offset of this lane's pixel rows (fixed)
+    int aoff[3];                                               // element offset of this lane's resident rows (fixed)
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int r = drow + 128 * q;
-        aoff[q] = (r < p.clip_rows && (q < 2 || xw)) ? (m0 + r) * p.pix_stride : -1;
+        int off = -1;
+        if (FACE) {
+            if (r < 18 * 18 && (q < 2 || xw)) {                // resident row r = padded pixel (r / 18, r % 18) of the face
+                const int cube = clip / 6, f = clip - cube * 6;
+                const CubePadGeom geom{16, 1, 1, 1, 1};
+                off = (cube * 6 * 256 + cubepad_src(f, r / 18, r - (r / 18) * 18, geom)) * p.pix_stride;
+            }
+        } else if (r < p.clip_rows && (q < 2 || xw)) {
+            off = (m0 + r) * p.pix_stride;
+        }
+        aoff[q] = off;
     }
 
     const int s_begin = split * p.sub_per_split;
@@ -1336,7 +1353,7 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     const int ml = lane & 15;
     if (!p.partial && (p.c_out % EPC == 0) && (p.ld_out % EPC == 0) && (p.out_coff % EPC == 0) &&
         (p.ld_res % EPC == 0)) {
-        epilogue_lds<T, BN, BM, MJ, 512, G::LDS_BYTES>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid, p.clip_rows);
+        epilogue_lds<T, BN, BM, MJ, 512, G::LDS_BYTES>(p, lds, acc, n0, m0, wch0, wrow0, lane, tid, rows_valid);
         return;
     }
 #pragma unroll
@@ -1346,7 +1363,7 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             const int row = wrow0 + j * 16 + ml;
-            if (row >= p.clip_rows) continue;
+            if (row >= rows_valid) continue;
             const int m = m0 + row;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.partial) {
@@ -1371,9 +1388,9 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     }
 }
 
-template <typename T>
+template <typename T, bool FACE>
 __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
-    typedef ClipGeom G;
+    typedef ClipGeom<FACE> G;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1396,9 +1413,11 @@ __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
         const CubePadGeom geom{n, 1, 1, 1, 1};
         for (int idx = tid; idx < 9 * 2 * 16 * 10; idx += 512) {
             const int j = idx % 10, lr = (idx / 10) % 16, g = (idx / 160) % 2, t = idx / 320;
-            const int row = g * 160 + j * 16 + lr;
+            const int row = g * G::GROUP_ROWS + j * 16 + lr;
             int src = 0;
-            if (row < p.clip_rows && (g == 0 || j < 9)) {
+            if (FACE) {
+                if (j < 8) src = ((row >> 4) + t / 3) * 18 + (row & 15) + t % 3;   // row of the padded 18x18 face
+            } else if (row < p.clip_rows && (g == 0 || j < 9)) {
                 const int f = row / nn, rem = row - f * nn;
                 const int y = rem / n, x = rem - y * n;
                 src = cubepad_src(f, y + t / 3, x + t % 3, geom);          // pixel index inside the clip
@@ -1408,8 +1427,13 @@ __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
         }
         __syncthreads();
     }
-    if (wave < 4) clip_body<T, 10, 5, false>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
-    else          clip_body<T, 9, 5, true>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+    if constexpr (FACE) {
+        if (wave < 4) clip_body<T, 8, 4, false, true>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 8, 4, true, true>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+    } else {
+        if (wave < 4) clip_body<T, 10, 5, false, false>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 9, 5, true, false>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+    }
 }
 
 // ------------------------------------------------------------------ split-K finish
@@ -1564,7 +1588,7 @@ static int check_desc(const cp360_conv_desc* d) {
     if (d->clip_resident != 0 && d->clip_resident != 1) return CP360_ERR_BAD_SHAPE;
     // clip-resident kernel: CubePad(1) + 3x3 stride 1 on faces whose cube (6 n^2 pixels) fits one 304-row tile
     if (d->clip_resident && !(d->pad_mode == 1 && d->pad == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 &&
-                              d->h_in == d->w_in && 6 * d->h_in * d->w_in <= 304 && d->c_out >= 256 &&
+                              d->h_in == d->w_in && (6 * d->h_in * d->w_in <= 304 || d->h_in == 16) && d->c_out >= 256 &&
                               d->pix_stride >= d->c_in && d->tile_px == 0))
         return CP360_ERR_UNSUPPORTED;
     if (d->c_in % epc != 0 || d->c_out % 4 != 0 || d->ld_out % 4 != 0 || d->out_coff % 4 != 0 || d->ld_res % 4 != 0)
@@ -1631,7 +1655,7 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
 static ConvPlan plan_of(const cp360_conv_desc* d) {
     if (d->clip_resident) {
         // one 256-channel x clip tile per workgroup, 64-byte sub-steps; about 0.9 us per sub-step
-        const int wgs = ((d->c_out + 255) / 256) * (d->n_img / 6);
+        const int wgs = ((d->c_out + 255) / 256) * (d->h_in == 16 ? d->n_img : d->n_img / 6);   // tile = face at 16x16
         const int nsub = 9 * (c_pad_of(d) / (bk_of(d->dtype) / 2));
         const double t_sub = d->dtype == CP360_F32 ? 2.7 : 0.9;
         const long long M = (long long)d->n_img * d->h_out * d->w_out;
@@ -1776,13 +1800,20 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     k.epi_direct = (epi_mode && epi_ok) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (d->clip_resident) {
+        const bool face = d->h_in == 16;                         // 16x16 faces: one face (+ its CubePad ring) per tile
         k.nt = (k.c_out + 255) / 256;
-        k.mt = d->n_img / 6;
+        k.mt = face ? d->n_img : d->n_img / 6;
         k.m_fast = 1;
         dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
-        if (d->dtype == CP360_F32) hipLaunchKernelGGL((conv_clip_kernel<float>), grid, dim3(512), 0, st, k);
-        else if (d->dtype == CP360_F16) hipLaunchKernelGGL((conv_clip_kernel<f16_raw>), grid, dim3(512), 0, st, k);
-        else hipLaunchKernelGGL((conv_clip_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+#define CP360_CLIP(TT)                                                                                    \
+        {                                                                                                     \
+            if (face) hipLaunchKernelGGL((conv_clip_kernel<TT, true>), grid, dim3(512), 0, st, k);            \
+            else      hipLaunchKernelGGL((conv_clip_kernel<TT, false>), grid, dim3(512), 0, st, k);           \
+        }
+        if (d->dtype == CP360_F32) CP360_CLIP(float)
+        else if (d->dtype == CP360_F16) CP360_CLIP(f16_raw)
+        else CP360_CLIP(bf16_raw)
+#undef CP360_CLIP
         CP360_CHECK_HIP();
         return CP360_OK;
     }

@@ -299,11 +299,11 @@ class Conv:
         ld_out = self.c_out if out is None else out.shape[3]
         ld_res = 0 if residual is None else residual.shape[3]
         L = lib()
-        # clip-resident kernel: whole cubes of <= 304 pixels (faces <= 7x7), no forced tile
+        # clip-resident kernel: whole cubes of <= 304 pixels (faces <= 7x7) or one 16x16 face + ring per tile
         cr = self.clip_resident_ok if clip_resident is None else bool(clip_resident)
-        cr = int(cr and h_in == w_in and 6 * h_in * w_in <= 304 and n_img % 6 == 0 and tile_px == 0)
+        cr = int(cr and h_in == w_in and (6 * h_in * w_in <= 304 or h_in == 16) and n_img % 6 == 0 and tile_px == 0)
         if clip_resident and not cr:
-            raise ValueError("clip_resident needs CubePad(1)+3x3 stride 1 on faces of at most 7x7")
+            raise ValueError("clip_resident needs CubePad(1)+3x3 stride 1 on faces of at most 7x7, or 16x16")
         if splits is None:
             key = (n_img, h_in, w_in, cr)
             splits = self._splits_cache.get(key)
