@@ -9,6 +9,15 @@
 // The CubePad(p) in front of every 3x3 conv (cube_pad.py:95-216) is NOT materialised:
 // src(m, tap) goes through cubepad_src() while the activation tile is gathered.
 //
+// Kernels in this file (the launch planner plan_of() picks one per call):
+//   conv_igemm_kernel<T,WN,WM>   c_out < 256: 128x128 / 64x256 tile, 4 waves, register-staged (described below)
+//   conv_igemm_dma_kernel<T,MJ>  c_out >= 256, small M: 256x128 tile, three LDS-DMA stages
+//   conv_igemm_ring_kernel<T,BM> c_out >= 256: 256x256 / 256x304 tile, four 64-byte-K stages, staggered waves
+//   conv_igemm_ring2_kernel<T>   1x1 with K of 128..512 elements, 16-bit: 256x128, two workgroups per CU
+//   conv_clip_kernel<T,FACE>     CubePad(1)+3x3 on 7x7 faces (ConvLSTM, one cube per tile) or 16x16 faces
+//                                (one face + ring per tile): activations LDS-resident, taps = row permutations
+// (the stem and layer1's conv2 have their own resident-tile kernels in stem.hip / band3x3.hip)
+//
 // Tiling (wave64, MFMA 16x16):
 //   workgroup = 4 waves, tile = (WN*64 output channels) x (WM*64 pixels), wave tile 64x64
 //   = 4x4 MFMA tiles, f32 accumulators (64 VGPRs).  MFMA "A" operand = weights (rows =
