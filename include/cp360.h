@@ -171,7 +171,8 @@ typedef struct {
     int clip_resident;/* 1: CubePad(1) + 3x3 stride-1 convolution on cube faces small
                          enough that a whole cube (6 n^2 <= 304 pixels, n <= 7: the
                          ConvLSTM of model/clstm.py at cube size 224) is one tile:
-                         the packed weights are channel-major ([c / 64 B][tap]) and
+                         the packed weights are channel- and tile-major
+                         ([n / 256][c / 64 B][tap][n % 256][64 B]) and
                          every tap reads the clip's activations from an LDS-resident
                          tile (cubepad halo never leaves the cube).  Also 16x16 faces
                          (cube size 512): one face per tile, resident with its CubePad
