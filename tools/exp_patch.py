@@ -61,9 +61,9 @@ for v in variants:
     if v == 'ring_nok':        # ring kernel: skip the K loop (epilogue only)
         sub('    const int nloc = s_end - s_begin;\n    const int sub_per_tap = 2 * p.steps_per_tap;', '    const int nloc = 0 * (s_end - s_begin);\n    const int sub_per_tap = 2 * p.steps_per_tap;')
     if v == 'clip_nw7':        # clip kernel: seven weight stages
-        sub('static constexpr int BN = 256, BM = 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = 304, NW = 7, NA = 2;')
+        sub('static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 7, NA = 2;')
     if v == 'clip_nw5':
-        sub('static constexpr int BN = 256, BM = 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = 304, NW = 5, NA = 2;')
+        sub('static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 5, NA = 2;')
     if v == 'clip_prio':       # clip kernel: static priority for the lagging half (waves 4-7)
         sub('    if (wave < 4) clip_body<T, 10, 5, false>', '    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    if (wave < 4) clip_body<T, 10, 5, false>')
     if v == 'fullline':
