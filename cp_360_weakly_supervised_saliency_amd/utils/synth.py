@@ -128,6 +128,34 @@ def fixation_map(seed, H=960, W=1920, sigma=15.0):
     return m
 
 
+def fixations_from_map(sal, seed, H=960, W=1920, n_near=24, n_far=6, top_k=12, sigma=None, jitter=0.3):
+    """Fixation map [H, W] float32 that is CORRELATED with a saliency map ``sal`` [h, w]
+    (normally the oracle's): ``n_near`` Gaussian blobs at the centres of its ``top_k``
+    highest cells, jittered by up to ``jitter`` cells, plus ``n_far`` blobs anywhere
+    (sigma defaults to 0.3 of a cell).  A map
+    judged against it scores AUC-Judd ~0.8-0.9 and CC >> 0, so |dAUC|, |dCC| <= 1e-3
+    discriminates (random blobs put both metrics at chance level, where any map
+    passes).  Deterministic given (sal, seed): ties are broken by flat index."""
+    sal = np.asarray(sal, dtype=np.float64)
+    h, w = sal.shape
+    if sigma is None:
+        sigma = 0.3 * H / float(h)
+    order = np.argsort(-sal.reshape(-1), kind='stable')[:top_k]
+    pick = hashrng.integers(seed, (n_near,), 0, top_k)
+    jy = hashrng.uniform(seed + 1, (n_near,), -jitter, jitter, dtype=np.float64)
+    jx = hashrng.uniform(seed + 2, (n_near,), -jitter, jitter, dtype=np.float64)
+    cy = (order[pick] // w + 0.5 + jy) * (H / float(h))
+    cx = (order[pick] % w + 0.5 + jx) * (W / float(w))
+    ys = np.concatenate([np.clip(cy, 0, H - 1), hashrng.integers(seed + 3, (n_far,), 0, H).astype(np.float64)])
+    xs = np.concatenate([np.mod(cx, W), hashrng.integers(seed + 4, (n_far,), 0, W).astype(np.float64)])
+    yy = np.arange(H, dtype=np.float32)[:, None]
+    xx = np.arange(W, dtype=np.float32)[None, :]
+    m = np.zeros((H, W), dtype=np.float32)
+    for y, x in zip(ys, xs):
+        m += np.exp(-((yy - np.float32(y)) ** 2 + (xx - np.float32(x)) ** 2) / np.float32(2 * sigma * sigma))
+    return m
+
+
 def cam_clip(seed, T, w=7, C=1000, scale=1000.0):
     """Synthetic stand-in for T consecutive cube_feat arrays [T,6,C,w,w] float32
     (smooth in t) for temporal-stage tests that do not run the ResNet."""

@@ -11,6 +11,13 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 
 def pytest_configure(config):
+    # the oracle is torch-CPU: on the GPU box's 256-thread host oneDNN is ~100x slower with all threads
+    # than with 32 (tools/cpu_threads_probe.py)
+    try:
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
 

@@ -662,9 +662,11 @@ def test_pipeline_c5_shape_fp32_and_fp16():
     from oracle import o_metrics
     eng16 = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision='fp16')
     sal16 = eng16(torch.from_numpy(clip[None]).to(DEV)).cpu().numpy()[0]
-    fix = synth.fixation_map(150, H // 2, W // 2)
+    fix = synth.fixations_from_map(ref, 150, H // 2, W // 2)     # correlated with the oracle map (not chance level)
     auc_ref = o_metrics.auc_judd(ref, fix, rng=np.random.RandomState(0))
     auc16 = o_metrics.auc_judd(sal16, fix, rng=np.random.RandomState(0))
     cc_ref, cc16 = o_metrics.corr_coeff(ref, fix), o_metrics.corr_coeff(sal16, fix)
     print('C5 fp16: max|d| %.3e dAUC %.3e dCC %.3e' % (np.max(np.abs(sal16 - ref)), auc16 - auc_ref, cc16 - cc_ref))
+    assert auc_ref > 0.7 and cc_ref > 0.05
     assert abs(auc16 - auc_ref) <= 1e-3 and abs(cc16 - cc_ref) <= 1e-3
+    assert o_metrics.corr_coeff(sal16, ref) >= 0.9999

@@ -1,6 +1,7 @@
 """Saliency metrics: CPU sanity of the oracle restatement, and the bf16
-acceptance gate on the GPU - AUC-Judd and CC of the build's map vs a synthetic fixation map
-must be within 1e-3 of the same metrics of the oracle's map."""
+acceptance gate on the GPU - AUC-Judd and CC of the build's map vs a fixation map sampled from
+the oracle's map must be within 1e-3 of the same metrics of the oracle's map, and
+CC(build, oracle) >= 0.9999."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +50,8 @@ def test_bf16_auc_cc_gate_full_size(T):
     cs = synth.clstm_state(seed=2)
     clip = synth.clip_u8(40, T, H, W)
     ref = oracle_pipeline(clip, rs, cs, cd)
-    fix = synth.fixation_map(140, H, W)
+    # fixations sampled from the oracle map: the oracle scores well above chance, so the 1e-3 gate discriminates
+    fix = synth.fixations_from_map(ref, 140, H // 2, W // 2)
     frames = torch.from_numpy(clip[None]).cuda()
 
     def metrics(m):
@@ -66,7 +68,9 @@ def test_bf16_auc_cc_gate_full_size(T):
         del eng
         torch.cuda.empty_cache()
     print('bf16/fp32 gate:', out, 'oracle AUC %.4f CC %.4f' % (auc_ref, cc_ref))
+    assert auc_ref > 0.7 and cc_ref > 0.1
     assert out['fp32'][0] <= 1e-3
+    assert min(out[p][3] for p in out) >= 0.9999, out          # CC(build, oracle)
     assert abs(out['fp32'][1]) <= 1e-3 and abs(out['fp32'][2]) <= 1e-3
     assert abs(out['bf16'][1]) <= 1e-3 and abs(out['bf16'][2]) <= 1e-3, out
     assert abs(out['fp16'][1]) <= 1e-3 and abs(out['fp16'][2]) <= 1e-3, out
