@@ -25,10 +25,12 @@ def precision_dtype(precision):
     except KeyError:
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
+# must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
+ABI_VERSION = 200
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
-    'cp360_strerror', 'cp360_version', 'cp360_cubepad_table_host', 'cp360_cubepad_nchw',
+    'cp360_strerror', 'cp360_version', 'cp360_conv_desc_bytes', 'cp360_cubepad_table_host', 'cp360_cubepad_nchw',
     'cp360_cubepad_nhwc', 'cp360_nchw_to_nhwc', 'cp360_nhwc_to_nchw', 'cp360_equi2cube',
     'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits',
     'cp360_conv_pack_weights', 'cp360_conv_forward', 'cp360_conv_finish',
@@ -66,6 +68,7 @@ def lib():
     L.cp360_strerror.restype = C.c_char_p
     L.cp360_strerror.argtypes = [i]
     L.cp360_version.restype = i
+    L.cp360_conv_desc_bytes.restype = sz
     L.cp360_cubepad_table_host.argtypes = [i, i, i, i, i, vp]
     L.cp360_cubepad_nchw.argtypes = [vp, vp, i, i, i, i, i, i, i, i, vp]
     L.cp360_cubepad_nhwc.argtypes = [vp, vp, i, i, i, i, i, i, i, i, i, vp]
@@ -98,6 +101,10 @@ def lib():
     L.cp360_band3x3_forward.argtypes = [i, vp, vp, vp, vp, i, i, i, i, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
+    if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):
+        raise ImportError("%s is a stale build: version %d / cp360_conv_desc %d bytes, the binding expects %d / %d "
+                          "- rebuild it (__graft_entry__.build())"
+                          % (LIB_PATH, L.cp360_version(), L.cp360_conv_desc_bytes(), ABI_VERSION, C.sizeof(ConvDesc)))
     _lib = L
     return L
 

@@ -163,4 +163,5 @@ extern "C" const char* cp360_strerror(int status) {
     }
 }
 
-extern "C" int cp360_version(void) { return 100; }
+extern "C" int cp360_version(void) { return CP360_VERSION; }
+extern "C" size_t cp360_conv_desc_bytes(void) { return sizeof(cp360_conv_desc); }

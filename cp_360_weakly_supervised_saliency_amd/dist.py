@@ -67,4 +67,7 @@ def max_over_ranks(value, device):
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == 'nccl':            # RCCL: name the device, or the barrier guesses it from the rank
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()

@@ -133,7 +133,13 @@ def cube2equi(x, face_map, coord, layout='nchw', want_full=True, want_max=False)
     """x f32 [6B, C, w, w] ('nchw') or [6B, w, w, C] ('nhwc'); face_map int8 [2w,4w];
     coord f32 [2w,4w,2] pixel-space sampling positions.  Returns (full, max)."""
     require_gpu(x, face_map, coord)
+    # the C ABI reads raw pointers as f32 / int8 / f32: anything else would be silently reinterpreted
+    if x.dtype != torch.float32:
+        raise ValueError("cube2equi samples f32 features (got %s): pass the f32 hidden state" % x.dtype)
+    if face_map.dtype != torch.int8 or coord.dtype != torch.float32:
+        raise ValueError("face_map must be int8 and coord f32 (got %s, %s)" % (face_map.dtype, coord.dtype))
     x = x.contiguous()
+    face_map, coord = face_map.contiguous(), coord.contiguous()
     if layout == 'nchw':
         n6, Cc, w, _ = x.shape
     else:
@@ -149,6 +155,23 @@ def cube2equi(x, face_map, coord, layout='nchw', want_full=True, want_max=False)
 
 
 # ----------------------------------------------------------------------------- convolution
+def _check_buf(name, t, dtype, min_shape=None, numel=None):
+    """A caller-provided destination / operand handed to the library as a raw pointer: wrong dtype,
+    strides or size would be an out-of-bounds device access, so fail in Python first."""
+    if t is None:
+        return
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if min_shape is not None:
+        if t.dim() != len(min_shape) or any(a != b for a, b in zip(t.shape[:-1], min_shape[:-1])) \
+                or t.shape[-1] < min_shape[-1]:
+            raise ValueError("%s has shape %s, needs %s (last dimension at least)" % (name, tuple(t.shape), tuple(min_shape)))
+    if numel is not None and t.numel() < numel:
+        raise ValueError("%s holds %d elements, needs %d" % (name, t.numel(), numel))
+
+
 # Optional launch timer (bench.py installs one): an object with
 # ``wrap(tag, flops, fn)`` that brackets the conv_forward launch with HIP events on the
 # current stream.  None = no instrumentation (default).
@@ -296,6 +319,9 @@ class Conv:
             raise ValueError("stem expects an NHWC4 input")
         h_out, w_out = self.out_hw(h_in, w_in)
         M = n_img * h_out * w_out
+        x = x.contiguous()
+        _check_buf('out', out, self.dtype, (n_img, h_out, w_out, self.c_out + out_coff))
+        _check_buf('residual', residual, self.dtype, (n_img, h_out, w_out, self.c_out))
         ld_out = self.c_out if out is None else out.shape[3]
         ld_res = 0 if residual is None else residual.shape[3]
         L = lib()
@@ -327,8 +353,8 @@ class Conv:
         if raw_f32 or splits > 1:
             need = splits * M * self.c_out
             if partial_buf is not None:          # caller-owned destination for the raw sums
-                if partial_buf.numel() < need or partial_buf.dtype != torch.float32:
-                    raise ValueError("partial_buf too small")
+                require_gpu(partial_buf)
+                _check_buf('partial_buf', partial_buf, torch.float32, numel=need)
                 check(forward(C.byref(d), ptr(x), ptr(packed), None, None, None,
                                            ptr(partial_buf), stream()))
                 return partial_buf, splits
@@ -361,15 +387,33 @@ def cubepad_maxpool3s2(x):
 
 
 def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, Hc, slab_rows=False):
+    require_gpu(partial, bias, c_prev, c_next, h_out, h_f32)
+    _check_buf('gates partial', partial, torch.float32, numel=splits * M * 4 * Hc)
+    _check_buf('gates bias', bias, torch.float32, numel=4 * Hc)
+    _check_buf('c_prev', c_prev, torch.float32, numel=M * Hc)
+    _check_buf('c_next', c_next, torch.float32, numel=M * Hc)
+    _check_buf('h_f32', h_f32, torch.float32, numel=M * Hc)
+    if not h_out.is_contiguous() or h_out.numel() < M * h_out.shape[-1] or h_coff + Hc > h_out.shape[-1]:
+        raise ValueError("h_out must be contiguous [.., ld] with M pixels and h_coff + Hc <= ld")
     check(lib().cp360_lstm_gates(ptr(partial), splits, ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out),
                                  dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc,
                                  int(slab_rows), stream()))
 
 
 def window_minmax(x, B, per_clip, minmax, scratch, clip_stride=0):
+    require_gpu(x, minmax, scratch)
+    _check_buf('x', x, torch.float32, numel=(B - 1) * (clip_stride or per_clip) + per_clip)
+    _check_buf('minmax', minmax, torch.float32, numel=2 * B)
+    _check_buf('scratch', scratch, torch.float32, numel=B * 256 * 2)
     check(lib().cp360_window_minmax(ptr(x), ptr(minmax), ptr(scratch), B, per_clip, clip_stride, stream()))
 
 
 def window_normalize(x, minmax, y, y_coff, y2, B, T, t, P, Cc, clip_stride=0):
+    require_gpu(x, minmax, y, y2)
+    _check_buf('x', x, torch.float32, numel=(B - 1) * (clip_stride or T * P * Cc) + (t + 1) * P * Cc)
+    _check_buf('minmax', minmax, torch.float32, numel=2 * B)
+    _check_buf('y2', y2, torch.float32, numel=B * P * Cc)
+    if not y.is_contiguous() or y.numel() < B * P * y.shape[-1] or y_coff + Cc > y.shape[-1]:
+        raise ValueError("y must be contiguous [.., ld] with B*P pixels and y_coff + C <= ld")
     check(lib().cp360_window_normalize(ptr(x), ptr(minmax), ptr(y), dtype_code(y.dtype), y.shape[-1], y_coff,
                                        ptr(y2), B, T, t, P, Cc, clip_stride, stream()))

@@ -30,7 +30,7 @@ from .utils.resize import LanczosResize
 class SaliencyEngine:
     def __init__(self, resnet_state, clstm_state, equi_hw=(1024, 2048), cube_dim=224, clips=1, frames=16,
                  precision='fp32', device='cuda', align_corners=False, cv_fixed_point=True,
-                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None):
+                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None, temporal_precision=None):
         self.device = torch.device(device)
         self.precision = precision
         self.dtype = _lib.precision_dtype(precision)
@@ -47,7 +47,9 @@ class SaliencyEngine:
         if bad or unexpected:
             raise KeyError("resnet state dict mismatch: missing %s unexpected %s" % (bad, unexpected))
         self.resnet.to(self.device).eval()
-        self.cell = ConvLSTMCell(input_size, hidden_size, precision=precision)
+        # the two stages meet at the f32 CAM scores, so each may run in its own arithmetic type
+        self.temporal_precision = temporal_precision or precision
+        self.cell = ConvLSTMCell(input_size, hidden_size, precision=self.temporal_precision)
         self.cell.load_state_dict(_to_tensors(clstm_state))           # strict, as test_temporal.py:149
         self.cell.to(self.device).eval()
         # decoded frames of another size are first resized as the reference does (PIL LANCZOS, K0)
@@ -84,12 +86,14 @@ class SaliencyEngine:
         """Record the whole path over ``frames`` (u8/f32 [B, T, H, W, 3] on the device) into a HIP
         graph.  Later ``__call__``s replay it: ~70 + 7*T kernel launches become one graph launch, which
         is what bounds single-frame / single-clip latency (BASELINE configs C2, C3).  The graph reads the
-        captured tensor's memory: calls with another tensor copy into it first."""
+        engine's OWN copy of the input (``frames`` is never written): every call copies its frames into that
+        static buffer first.  The returned maps alias the graph's output buffer and are overwritten by the
+        next call - clone them to keep them."""
         with torch.no_grad():
             self._graph = None
             self._forward(frames)                       # warm-up: packs weights, sizes every buffer
             torch.cuda.synchronize()
-            self._graph_in = frames
+            self._graph_in = frames.clone()             # engine-owned static input (the caller's tensor stays untouched)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._graph_out = self._forward(self._graph_in)
@@ -107,8 +111,9 @@ class SaliencyEngine:
         """frames [B, T, H, W, 3] (u8 or f32, device) -> saliency f32 [B, 2w, 4w]."""
         with torch.no_grad():
             if getattr(self, '_graph', None) is not None:
-                if frames.data_ptr() != self._graph_in.data_ptr():
-                    self._graph_in.copy_(frames)
+                if frames.shape != self._graph_in.shape or frames.dtype != self._graph_in.dtype:
+                    raise ValueError("graph captured for %s %s frames" % (tuple(self._graph_in.shape), self._graph_in.dtype))
+                self._graph_in.copy_(frames)
                 self._graph.replay()
                 return self._graph_out
             return self._forward(frames)

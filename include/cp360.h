@@ -50,8 +50,13 @@ typedef enum {
 } cp360_dtype;
 
 const char* cp360_strerror(int status);
-/* library / ABI version: major*10000 + minor*100 + patch */
+/* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
+ * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
+ * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
+#define CP360_VERSION 200
 int cp360_version(void);
+/* sizeof(cp360_conv_desc) as the library was compiled. */
+size_t cp360_conv_desc_bytes(void);
 
 /* ------------------------------------------------------------------ K2: CubePad
  * Replaces CubePad.forward / CubePadding.forward, model/cube_pad.py:28-42,95-216

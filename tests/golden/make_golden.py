@@ -6,7 +6,7 @@ reference is imported in memory with the shims listed in SURVEY.md section 8(c);
 nothing of its source is written to this repo - the fixtures are inputs (or their
 hash-RNG seeds) and the reference's outputs.
 
-    python tests/golden/make_golden.py [--only cubepad,e2c,c2e,resnet,clstm]
+    python tests/golden/make_golden.py [--only cubepad,e2c,c2e,resnet,clstm,resize,metrics]
 
 Shims (all in memory):
   * ``np.int = int``  (alias removed in numpy >= 1.24; cube_pad.py:13,64)
@@ -262,9 +262,49 @@ def gen_resize(out):
     np.savez_compressed(os.path.join(out, 'resize_lanczos.npz'), **arrs)
 
 
+# --------------------------------------------------------------------------- metrics (f1)
+METRIC_CASES = [((14, 28), (480, 960)), ((32, 64), (512, 1024)), ((120, 240), (120, 240)), ((16, 32), (100, 200))]
+
+
+def metric_inputs(k):
+    """Seeded (saliency, ground-truth) pair of case k: a hash-noise saliency map and a fixation
+    map correlated with it (float32; the reference feeds float .npy maps, test_temporal.py:101-110)."""
+    (h, w), (H, W) = METRIC_CASES[k]
+    sal = hashrng.uniform(8000 + k, (h, w)) ** 2
+    gt = synth.fixations_from_map(sal, 8100 + k, H, W)
+    return sal.astype(np.float32), gt.astype(np.float32)
+
+
+def gen_metrics(R, out):
+    """utils/eval_saliency.py:14-190 executed from the reference with two in-memory shims: ``cv2.resize``
+    = the oracle's restated INTER_LINEAR resize (cv2 is absent; the reference passes INTER_LANCZOS4 in the
+    ``dst`` slot, so the default bilinear runs) and a stub for ``utils.cube_to_equi`` (a SyntaxError on
+    Python >= 3.7, not used by the metric functions).  Pins the numpy arithmetic of AUC_Judd / CorrCoeff /
+    similarity / AUC_Borji; the resize itself stays unpinned (third party)."""
+    from oracle import o_metrics
+    cv2 = sys.modules['cv2']
+    cv2.INTER_LANCZOS4 = 4
+    cv2.resize = lambda src, dsize, *a, **k: np.array(o_metrics.resize_linear(src, dsize), copy=True)
+    sys.modules.setdefault('utils.cube_to_equi', R['c2e'])
+    np.trapz = getattr(np, 'trapz', None) or np.trapezoid          # removed alias in numpy >= 2.? (shim)
+    import importlib
+    ev = importlib.import_module('utils.eval_saliency')
+    arrs = {}
+    for k in range(len(METRIC_CASES)):
+        sal, gt = metric_inputs(k)
+        np.random.seed(0)
+        arrs['auc_judd_%d' % k] = np.float64(ev.AUC_Judd(sal.copy(), gt.copy()))
+        arrs['cc_%d' % k] = np.float64(ev.CorrCoeff(sal.copy(), gt.copy()))
+        arrs['sim_%d' % k] = np.float64(ev.similarity(sal.copy(), gt.copy()))
+        np.random.seed(0)
+        arrs['auc_borji_%d' % k] = np.float64(ev.AUC_Borji(sal.copy(), gt.copy(), Nsplits=10))
+    np.savez_compressed(os.path.join(out, 'metrics.npz'), **arrs)
+    print('metrics fixtures written', {k: float(v) for k, v in arrs.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='cubepad,e2c,c2e,resnet,clstm,resize')
+    ap.add_argument('--only', default='cubepad,e2c,c2e,resnet,clstm,resize,metrics')
     args = ap.parse_args()
     parts = args.only.split(',')
     if 'resize' in parts:                      # Pillow only: the reference itself is not needed
@@ -276,7 +316,7 @@ def main():
     R['torch'].set_num_threads(8)
     for part in parts:
         {'cubepad': gen_cubepad, 'e2c': gen_e2c, 'c2e': gen_c2e,
-         'resnet': gen_resnet, 'clstm': gen_clstm}[part](R, HERE)
+         'resnet': gen_resnet, 'clstm': gen_clstm, 'metrics': gen_metrics}[part](R, HERE)
 
 
 if __name__ == '__main__':

@@ -22,7 +22,9 @@ def test_library_exports_every_header_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libcp360.so does not export %s" % name
     assert declared == set(_lib.SYMBOLS)
-    assert L.cp360_version() >= 100
+    hv = int(re.search(r'#define\s+CP360_VERSION\s+(\d+)', hdr).group(1))
+    assert L.cp360_version() == hv == _lib.ABI_VERSION           # header, library and binding agree
+    assert L.cp360_conv_desc_bytes() == C.sizeof(_lib.ConvDesc)
     assert L.cp360_strerror(-2).decode().startswith('CubePad size mismatch')
 
 

@@ -72,3 +72,23 @@ def test_shard_is_balanced_partition():
             assert sum(parts, []) == list(range(n))
             sizes = [len(p) for p in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('n_clips', [8, 5])
+def test_torchrun_launcher_contract(n_clips):
+    """The launcher / environment contract bench.py relies on for N > 1 (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_* set by ``python -m torch.distributed.run``): two ranks started by the real launcher go
+    through init_from_env -> shard_clips -> gather_maps -> max_over_ranks and rank 0 prints the JSON line."""
+    import json
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(REPO, 'tests', '_torchrun_worker.py'), str(n_clips)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout                     # exactly one line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['clips'] == n_clips and out['gathered_equal_single_process'] is True
+    assert out['max_elapsed'] == 1.5 and out['backend'] == 'gloo'

@@ -37,6 +37,22 @@ def test_metric_sanity():
         o_metrics.auc_judd(good, np.zeros_like(fix))
 
 
+def test_oracle_metrics_match_reference_goldens(golden_dir):
+    """tests/golden/metrics.npz holds AUC_Judd / CorrCoeff / similarity / AUC_Borji as computed by the
+    reference's own utils/eval_saliency.py (make_golden.py: gen_metrics) on seeded maps; the oracle
+    restatement must reproduce them (same resize, same RandomState(0) stream)."""
+    import os
+    from tests.golden.make_golden import METRIC_CASES, metric_inputs
+    g = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    for k in range(len(METRIC_CASES)):
+        sal, gt = metric_inputs(k)
+        assert abs(o_metrics.auc_judd(sal, gt, rng=np.random.RandomState(0)) - float(g['auc_judd_%d' % k])) <= 1e-12
+        assert abs(o_metrics.corr_coeff(sal, gt) - float(g['cc_%d' % k])) <= 1e-6
+        assert abs(o_metrics.similarity(sal, gt) - float(g['sim_%d' % k])) <= 1e-7
+        assert abs(o_metrics.auc_borji(sal, gt, n_splits=10, rng=np.random.RandomState(0))
+                   - float(g['auc_borji_%d' % k])) <= 1e-12
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('T', [5, 16])
 def test_bf16_auc_cc_gate_full_size(T):
