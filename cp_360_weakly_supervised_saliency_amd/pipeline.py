@@ -30,10 +30,17 @@ from .utils.resize import LanczosResize
 class SaliencyEngine:
     def __init__(self, resnet_state, clstm_state, equi_hw=(1024, 2048), cube_dim=224, clips=1, frames=16,
                  precision='fp32', device='cuda', align_corners=False, cv_fixed_point=True,
-                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None, temporal_precision=None):
+                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None, static_precision=None):
         self.device = torch.device(device)
+        # ``precision`` is the arithmetic type of the temporal stage (the ConvLSTM: 81 % of the flops);
+        # ``static_precision`` that of the static stage (cube projection output, ResNet-50, CAM conv).  The
+        # stages meet at the f32 CAM scores.  A bf16 engine runs the static stage in fp16 by default: same
+        # MFMA rate and bytes, 3 more mantissa bits - measured on a 1024x2048 T=16 clip against the oracle
+        # (tools/exp_precision_split.py): bf16 ResNet -> map max|d| 3.4e-3, dCC 1.2e-3 whatever the ConvLSTM
+        # runs in; fp16 ResNet + bf16 ConvLSTM -> 5.2e-4, dCC 2.2e-4.
         self.precision = precision
-        self.dtype = _lib.precision_dtype(precision)
+        self.static_precision = static_precision or ('fp16' if precision == 'bf16' else precision)
+        self.dtype = _lib.precision_dtype(self.static_precision)
         self.B, self.T = int(clips), int(frames)
         self.H, self.W = equi_hw
         self.cube_dim = int(cube_dim)
@@ -41,15 +48,13 @@ class SaliencyEngine:
         # frames per static-stage launch group (bounds activation memory; None = all)
         self.frame_chunk = frame_chunk or self.B * self.T
 
-        self.resnet = resnet50(precision=precision)
+        self.resnet = resnet50(precision=self.static_precision)
         missing, unexpected = self.resnet.load_state_dict(_to_tensors(resnet_state), strict=False)
         bad = [k for k in missing if not k.endswith('num_batches_tracked')]
         if bad or unexpected:
             raise KeyError("resnet state dict mismatch: missing %s unexpected %s" % (bad, unexpected))
         self.resnet.to(self.device).eval()
-        # the two stages meet at the f32 CAM scores, so each may run in its own arithmetic type
-        self.temporal_precision = temporal_precision or precision
-        self.cell = ConvLSTMCell(input_size, hidden_size, precision=self.temporal_precision)
+        self.cell = ConvLSTMCell(input_size, hidden_size, precision=precision)
         self.cell.load_state_dict(_to_tensors(clstm_state))           # strict, as test_temporal.py:149
         self.cell.to(self.device).eval()
         # decoded frames of another size are first resized as the reference does (PIL LANCZOS, K0)

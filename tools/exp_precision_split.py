@@ -23,7 +23,7 @@ a0, c0 = m(ref)
 print('oracle: AUC %.4f CC %.4f range [%.4f, %.4f]' % (a0, c0, ref.min(), ref.max()))
 frames = torch.from_numpy(clip[None]).cuda()
 for sp, tp in (('fp32', 'fp32'), ('bf16', 'bf16'), ('fp32', 'bf16'), ('bf16', 'fp32'), ('fp16', 'fp16'), ('fp16', 'bf16'), ('bf16', 'fp16')):
-    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision=sp, temporal_precision=tp)
+    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision=tp, static_precision=sp)
     sal = eng(frames).cpu().numpy()[0]
     a, c = m(sal)
     d = sal - ref
