@@ -26,14 +26,15 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 200
+ABI_VERSION = 201
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
     'cp360_strerror', 'cp360_version', 'cp360_conv_desc_bytes', 'cp360_cubepad_table_host', 'cp360_cubepad_nchw',
     'cp360_cubepad_nhwc', 'cp360_nchw_to_nhwc', 'cp360_nhwc_to_nchw', 'cp360_equi2cube',
     'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits',
-    'cp360_conv_pack_weights', 'cp360_conv_forward', 'cp360_conv_finish',
+    'cp360_conv_pack_weights', 'cp360_conv_pack_weights2', 'cp360_conv_forward', 'cp360_conv_forward2',
+    'cp360_conv_finish',
     'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_window_minmax',
     'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes', 'cp360_band3x3_pack_weights', 'cp360_band3x3_forward',
 ]
@@ -44,7 +45,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         'dtype', 'n_img', 'h_in', 'w_in', 'c_in', 'pix_stride', 'kh', 'kw', 'sy', 'sx',
         'h_out', 'w_out', 'c_out', 'pad_mode', 'pad', 'ld_out', 'out_coff', 'ld_res',
-        'relu', 'splits', 'tile_px', 'clip_resident', 'slab_rows')]
+        'relu', 'splits', 'tile_px', 'clip_resident', 'slab_rows',
+        'c_in2', 'pix_stride2', 'h_in2', 'w_in2', 'sy2', 'sx2')]
 
 
 class Cp360Error(RuntimeError):
@@ -83,6 +85,8 @@ def lib():
     L.cp360_conv_suggest_splits.argtypes = [pd]
     L.cp360_conv_pack_weights.argtypes = [pd, vp, vp, vp, i, vp]
     L.cp360_conv_forward.argtypes = [pd, vp, vp, vp, vp, vp, vp, vp]
+    L.cp360_conv_pack_weights2.argtypes = [pd, vp, vp, vp, vp, vp, vp]
+    L.cp360_conv_forward2.argtypes = [pd, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cp360_conv_finish.argtypes = [pd, vp, vp, vp, vp, vp]
     L.cp360_cubepad_maxpool3s2.argtypes = [vp, vp, i, i, i, i, vp]
     L.cp360_lstm_gates.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, i, vp]

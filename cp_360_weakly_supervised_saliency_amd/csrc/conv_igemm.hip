@@ -57,6 +57,11 @@ struct ConvK {
     int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
     int epi_direct;                       // 1: direct 16-byte epilogue, 0: LDS-staged epilogue
     int slab_rows;                        // 1: split-K slabs in packed-row column order (slab_col)
+    // second source (cp360_conv_desc.c_in2 > 0): one extra 1x1 "tap" (index kh*kw, packed behind the others)
+    // gathered from in2 [n_img, h_in2, w_in2, pix_stride2] at (oy * sy2, ox * sx2) - the Bottleneck's downsample
+    // branch accumulated into the conv3 tile (ring kernels only)
+    const unsigned char* in2;
+    int c_in2, c_pad2, pix_stride2, h_in2, w_in2, sy2, sx2, ntap;
 };
 
 template <typename T> struct Elem;
@@ -871,6 +876,7 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
     const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
     auto set_tap = [&](int tap) __attribute__((always_inline)) {
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const bool sec = tap >= p.ntap;                        // the second source's tap (wave-uniform)
 #pragma unroll
         for (int pb = 0; pb < B_PASSES; ++pb) {
             const int m = m0 + drow + 128 * pb;
@@ -880,6 +886,11 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
                 const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
                 const int py = oy * p.sy + ky, px = ox * p.sx + kx;
                 int pix;
+                if (sec) {
+                    off = ((img * p.h_in2 + oy * p.sy2) * p.w_in2 + ox * p.sx2) * p.pix_stride2;
+                    roff[pb] = off;
+                    continue;
+                }
                 if (p.pad_mode) {
                     const int grp = img / 6, f = img - grp * 6;
                     pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
@@ -897,10 +908,11 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
     const int s_end = 2 * min(p.nsteps, (split + 1) * p.steps_per_split);
     const int nloc = s_end - s_begin;
     const int sub_per_tap = 2 * p.steps_per_tap;
-    int tap = s_begin / sub_per_tap;
+    int tap = min(s_begin / sub_per_tap, p.ntap);              // ntap = the second source's tap (if any)
     int c0 = (s_begin - tap * sub_per_tap) * BKS;
 
     const T* in = reinterpret_cast<const T*>(p.in);
+    const T* in2 = reinterpret_cast<const T*>(p.in2);
     const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + drow) * p.k_total + dchunk * EPC;
     const size_t wpass = (size_t)128 * p.k_total;
     const unsigned lds_base = (unsigned)(size_t)lds;
@@ -913,8 +925,9 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
         } else {
             const int pb = q - A_PASSES;
             const int e = c0 + dchunk * EPC;
-            const bool ok = e < p.c_in && roff[pb] >= 0;
-            const T* src = ok ? in + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
+            const bool sec = tap >= p.ntap;
+            const bool ok = e < (sec ? p.c_in2 : p.c_in) && roff[pb] >= 0;
+            const T* src = ok ? (sec ? in2 : in) + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
             glds16(src, sbase + BN * 64 + pb * 128 * 64);
         }
     };
@@ -926,7 +939,7 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
     };
     auto advance = [&]() __attribute__((always_inline)) {
         c0 += BKS;
-        if (c0 >= p.c_pad) {
+        if (c0 >= p.c_pad && tap < p.ntap) {                   // (the second source's tap is the last one)
             c0 = 0;
             ++tap;
             set_tap(tap);
@@ -1532,14 +1545,22 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                                            T* __restrict__ packed, int c_out, int c_out_pad, int c_in,
-                                                           int c_pad, int kh, int kw, int stem_mode, int chan_major) {
+                                                           int c_pad, int kh, int kw, int stem_mode, int chan_major,
+                                                           const float* __restrict__ w2, const float* __restrict__ scale2,
+                                                           int c_in2, int c_pad2) {
     const int taps = kh * kw;
     constexpr int BKS = 64 / (int)sizeof(T);          // elements per 64-byte sub-step
-    const long long total = (long long)c_out_pad * taps * c_pad;
+    const int ktot = taps * c_pad + c_pad2;           // c_pad2 > 0: the second source's 1x1 filter behind the taps
+    const long long total = (long long)c_out_pad * ktot;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         int c, tap, n;
-        if (chan_major) {   // [n / 256][c / BKS][tap][n % 256][BKS]   (c_pad is a multiple of BKS here): the
+        if (c_pad2 > 0) {   // [n][tap][c_pad] ... [c_pad2]  (tap-major only)
+            const int k = (int)(idx % ktot);
+            n = (int)(idx / ktot);
+            tap = k / c_pad;
+            c = k - tap * c_pad;
+        } else if (chan_major) {   // [n / 256][c / BKS][tap][n % 256][BKS]   (c_pad is a multiple of BKS here): the
             // 256 rows x 64 bytes one workgroup needs per sub-step are ONE contiguous 16 KiB block
             const int e = (int)(idx % BKS);
             long long t = idx / BKS;
@@ -1559,7 +1580,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         // n is the packed row; its channel (acc_chan): row 32q + 16b + 4g + e <- channel 32q + 8g + 4b + e
         n = (n & ~31) + ((n >> 2) & 3) * 8 + ((n >> 4) & 1) * 4 + (n & 3);
         float v = 0.f;
-        if (n < c_out) {
+        if (n < c_out && tap >= taps) {                // second source: [c_out, c_in2] filter
+            if (c < c_in2) v = w2[(size_t)n * c_in2 + c] * (scale2 ? scale2[n] : 1.f);
+        } else if (n < c_out) {
             if (stem_mode) {   // desc kh=7, kw=1, c_in=32: k = kx*4 + ch of a [c_out,3,7,7] filter
                 const int kx = c >> 2, ch = c & 3, ky = tap;
                 if (c < c_in && kx < 7 && ch < 3) v = w[(((size_t)n * 3 + ch) * 7 + ky) * 7 + kx];
@@ -1587,6 +1610,7 @@ static int c_pad_of(const cp360_conv_desc* d) {
     return (d->c_in + unit - 1) / unit * unit;
 }
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static int c_pad2_of(const cp360_conv_desc* d) { return d->c_in2 > 0 ? round_up(d->c_in2, bk_of(d->dtype)) : 0; }
 
 static int check_desc(const cp360_conv_desc* d) {
     if (!d) return CP360_ERR_NULL;
@@ -1607,6 +1631,15 @@ static int check_desc(const cp360_conv_desc* d) {
                               d->h_in == d->w_in && (6 * d->h_in * d->w_in <= 304 || d->h_in == 16) && d->c_out >= 256 &&
                               d->pix_stride >= d->c_in && d->tile_px == 0))
         return CP360_ERR_UNSUPPORTED;
+    if (d->c_in2 < 0) return CP360_ERR_BAD_SHAPE;
+    if (d->c_in2 > 0) {    // second source: ring kernels only (c_out >= 256), no clip-resident / stem forms
+        if (d->clip_resident || d->c_out < 256 || d->pix_stride < d->c_in) return CP360_ERR_UNSUPPORTED;
+        if (d->c_in2 % epc != 0) return CP360_ERR_ALIGN;
+        if (d->pix_stride2 < d->c_in2 || d->h_in2 <= 0 || d->w_in2 <= 0 || d->sy2 <= 0 || d->sx2 <= 0 ||
+            (d->h_out - 1) * d->sy2 >= d->h_in2 || (d->w_out - 1) * d->sx2 >= d->w_in2)
+            return CP360_ERR_BAD_SHAPE;
+        if ((long long)d->n_img * d->h_in2 * d->w_in2 * d->pix_stride2 >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    }
     if (d->c_in % epc != 0 || d->c_out % 4 != 0 || d->ld_out % 4 != 0 || d->out_coff % 4 != 0 || d->ld_res % 4 != 0)
         return CP360_ERR_ALIGN;
     if (d->ld_out < d->c_out + d->out_coff) return CP360_ERR_BAD_SHAPE;
@@ -1627,7 +1660,7 @@ static int check_desc(const cp360_conv_desc* d) {
 
 extern "C" size_t cp360_conv_packed_bytes(const cp360_conv_desc* d) {
     if (check_desc(d)) return 0;
-    return (size_t)round_up(d->c_out, 256) * d->kh * d->kw * c_pad_of(d) * elem_bytes(d->dtype);
+    return (size_t)round_up(d->c_out, 256) * ((size_t)d->kh * d->kw * c_pad_of(d) + c_pad2_of(d)) * elem_bytes(d->dtype);
 }
 
 extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
@@ -1650,7 +1683,7 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
     const long long M = (long long)d->n_img * d->h_out * d->w_out;
     const long long wgs = ((d->c_out + bn - 1) / bn) * ((M + bm - 1) / bm);
     const int bk = bk_of(d->dtype);
-    const int nsteps = d->kh * d->kw * (round_up(d->c_in, bk) / bk);
+    const int nsteps = d->kh * d->kw * (round_up(d->c_in, bk) / bk) + c_pad2_of(d) / bk;
     if (d->dtype == CP360_F32) t_step *= 3.0;
     const double t_fixed = 4.0;
     ConvPlan best{bn, bm, slots, 1, 0.0};
@@ -1705,12 +1738,14 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
         return e ? atoi(e) : 1;
     }();
     // (K of at least two 128-byte steps: at K = 64 elements the one-workgroup 256x304 tile measured faster)
-    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && d->c_in * elem_bytes(d->dtype) >= 256 &&
-        d->c_in * elem_bytes(d->dtype) <= 1024) {
+    const int kbytes = (d->c_in + d->c_in2) * elem_bytes(d->dtype);
+    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && kbytes >= 256 && kbytes <= 1024) {
         ConvPlan r2 = plan_candidate(d, 256, 128, 512, 1.25);
         r2.bm = 129;
         if (r2.cost < best.cost) best = r2;
     }
+    // the 3-stage 256x128 DMA kernel has no second-source loader: its ring equivalents take over
+    if (d->c_in2 > 0 && best.bm == 128) best.bm = d->dtype == CP360_F32 ? 256 : 129;
     return best;
 }
 
@@ -1738,8 +1773,24 @@ extern "C" int cp360_conv_suggest_splits(const cp360_conv_desc* d) {
     return plan_of(&t).splits;
 }
 
+static int pack_weights_impl(const cp360_conv_desc* d, const float* w_oihw, const float* scale, const float* w2,
+                             const float* scale2, void* packed, int stem_mode, void* stream);
+
 extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const float* scale, void* packed,
                                        int stem_mode, void* stream) {
+    if (d && d->c_in2 > 0) return CP360_ERR_NULL;              // a second source needs its filter: cp360_conv_pack_weights2
+    return pack_weights_impl(d, w_oihw, scale, nullptr, nullptr, packed, stem_mode, stream);
+}
+
+extern "C" int cp360_conv_pack_weights2(const cp360_conv_desc* d, const float* w_oihw, const float* scale,
+                                        const float* w2_oi, const float* scale2, void* packed, void* stream) {
+    if (!d || d->c_in2 <= 0) return CP360_ERR_BAD_SHAPE;
+    if (!w2_oi) return CP360_ERR_NULL;
+    return pack_weights_impl(d, w_oihw, scale, w2_oi, scale2, packed, 0, stream);
+}
+
+static int pack_weights_impl(const cp360_conv_desc* d, const float* w_oihw, const float* scale, const float* w2,
+                             const float* scale2, void* packed, int stem_mode, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!w_oihw || !packed) return CP360_ERR_NULL;
@@ -1747,19 +1798,23 @@ extern "C" int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_
     if (stem_mode && d->clip_resident) return CP360_ERR_UNSUPPORTED;
     const int c_pad = c_pad_of(d);
     const int c_out_pad = round_up(d->c_out, 256);
-    const long long total = (long long)c_out_pad * d->kh * d->kw * c_pad;
+    const int c_pad2 = c_pad2_of(d);
+    const long long total = (long long)c_out_pad * ((long long)d->kh * d->kw * c_pad + c_pad2);
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == CP360_F32)
         hipLaunchKernelGGL((pack_weights_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
-                           (float*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident);
+                           (float*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident,
+                           w2, scale2, d->c_in2, c_pad2);
     else if (d->dtype == CP360_F16)
         hipLaunchKernelGGL((pack_weights_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
-                           (f16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident);
+                           (f16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident,
+                           w2, scale2, d->c_in2, c_pad2);
     else
         hipLaunchKernelGGL((pack_weights_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, scale,
-                           (bf16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident);
+                           (bf16_raw*)packed, d->c_out, c_out_pad, d->c_in, c_pad, d->kh, d->kw, stem_mode, d->clip_resident,
+                           w2, scale2, d->c_in2, c_pad2);
     CP360_CHECK_HIP();
     return CP360_OK;
 }
@@ -1776,9 +1831,15 @@ static void launch_conv(ConvK& k, hipStream_t st) {
 
 extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, const void* packed_w, const float* bias,
                                   const void* residual, void* out, float* partial, void* stream) {
+    return cp360_conv_forward2(d, in, nullptr, packed_w, bias, residual, out, partial, stream);
+}
+
+extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, const void* in2, const void* packed_w,
+                                   const float* bias, const void* residual, void* out, float* partial, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!in || !packed_w) return CP360_ERR_NULL;
+    if ((d->c_in2 > 0) != (in2 != nullptr)) return CP360_ERR_NULL;
     if (d->splits > 1 && !partial) return CP360_ERR_NULL;
     if (d->splits == 1 && !out && !partial) return CP360_ERR_NULL;
     if (residual && d->ld_res < d->c_out) return CP360_ERR_BAD_SHAPE;
@@ -1798,9 +1859,13 @@ extern "C" int cp360_conv_forward(const cp360_conv_desc* d, const void* in, cons
     const int bk = bk_of(d->dtype);
     k.c_pad = c_pad_of(d);
     k.steps_per_tap = k.c_pad / bk;                              // 128-byte steps (tap-major layout only)
-    k.nsteps = d->kh * d->kw * k.steps_per_tap;
+    k.in2 = (const unsigned char*)in2;
+    k.c_in2 = d->c_in2; k.c_pad2 = c_pad2_of(d); k.pix_stride2 = d->pix_stride2; k.h_in2 = d->h_in2; k.w_in2 = d->w_in2;
+    k.sy2 = d->sy2; k.sx2 = d->sx2;
+    k.ntap = d->kh * d->kw;
+    k.nsteps = d->kh * d->kw * k.steps_per_tap + k.c_pad2 / bk;
     k.steps_per_split = (k.nsteps + d->splits - 1) / d->splits;
-    k.k_total = d->kh * d->kw * k.c_pad;
+    k.k_total = d->kh * d->kw * k.c_pad + k.c_pad2;
     k.slab_rows = d->slab_rows;
     k.clip_rows = 6 * d->h_out * d->w_out;
     k.nsub = k.k_total / (bk / 2);

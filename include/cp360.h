@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 200
+#define CP360_VERSION 201
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -189,6 +189,14 @@ typedef struct {
                          a pixel's lanes store 64 contiguous bytes; cp360_conv_finish
                          (same desc) and cp360_lstm_gates(slab_rows = 1) read that order.
                          Needs c_out % 32 == 0.  0: true channel order (raw CAM scores) */
+    /* --- second source (0 = none): one more 1x1 filter accumulated into the same output tile, gathered
+       from a second tensor in2 [n_img, h_in2, w_in2, pix_stride2] at pixel (oy * sy2, ox * sx2):
+       out = act(conv(in) + W2 . in2 + bias (+ residual)).  This is the Bottleneck's downsample branch
+       (model/resnet_cubic.py:99-104: conv1x1(stride) + BatchNorm on the block input, added to bn3's output
+       before the ReLU) computed inside conv3's tile, so its [M, c_out] result never goes through HBM.
+       Needs c_out >= 256, no clip_resident; pack with cp360_conv_pack_weights2, run with
+       cp360_conv_forward2. */
+    int c_in2, pix_stride2, h_in2, w_in2, sy2, sx2;
 } cp360_conv_desc;
 
 /* Bytes of packed weights for a desc (rows padded to the tile, K padded per tap). */
@@ -203,6 +211,10 @@ size_t cp360_conv_partial_bytes(const cp360_conv_desc* d);
  * (k index = kx*4 + c). */
 int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const float* scale,
                             void* packed, int stem_mode, void* stream);
+/* Same with a second source (d->c_in2 > 0): w2_oi f32 [c_out, c_in2] times scale2[c_out] is packed behind
+ * the taps of the first filter. */
+int cp360_conv_pack_weights2(const cp360_conv_desc* d, const float* w_oihw, const float* scale,
+                             const float* w2_oi, const float* scale2, void* packed, void* stream);
 /* out = act(conv(in) + bias (+ residual)).  bias f32 [c_out] or NULL.
  * d->splits > 1, or out == NULL: the raw f32 sums go to `partial`
  * ([splits, M, c_out], M = n_img*h_out*w_out; bias / residual / relu NOT applied)
@@ -210,6 +222,10 @@ int cp360_conv_pack_weights(const cp360_conv_desc* d, const float* w_oihw, const
 int cp360_conv_forward(const cp360_conv_desc* d, const void* in, const void* packed_w,
                        const float* bias, const void* residual, void* out,
                        float* partial, void* stream);
+/* cp360_conv_forward with the second source in2 (NULL iff d->c_in2 == 0). */
+int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, const void* in2, const void* packed_w,
+                        const float* bias, const void* residual, void* out,
+                        float* partial, void* stream);
 /* out = act(sum_s partial[s] + bias (+ residual)) in d->dtype at the desc's ld_out/out_coff. */
 int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const float* bias,
                       const void* residual, void* out, void* stream);
