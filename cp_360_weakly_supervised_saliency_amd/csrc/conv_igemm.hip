@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         if (c_pad2 > 0) {   // [n][tap][c_pad] ... [c_pad2]  (tap-major only)
             const int k = (int)(idx % ktot);
             n = (int)(idx / ktot);
-            tap = k / c_pad;
+            tap = min(k / c_pad, taps);            // taps = the second source's region (c_pad2 wide)
             c = k - tap * c_pad;
         } else if (chan_major) {   // [n / 256][c / BKS][tap][n % 256][BKS]   (c_pad is a multiple of BKS here): the
             // 256 rows x 64 bytes one workgroup needs per sub-step are ONE contiguous 16 KiB block
@@ -1902,6 +1902,10 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     int bn_ = 0, bm_ = 0, slots_ = 0;
     if (d->c_out >= 256) tile_of(d, &bn_, &bm_, &slots_);
     const bool wide = d->c_out >= 256 && bn_ == 256;           // else: the 4-wave 128x128 kernel, two workgroups per CU
+    if (d->c_in2 > 0) {                                        // second source: ring kernels only
+        if (!wide) return CP360_ERR_UNSUPPORTED;
+        if (bm_ == 128) bm_ = d->dtype == CP360_F32 ? 256 : 129;
+    }
     if (wide) {
         // 256x256 tiles carry 1.5x the flops per byte brought into the CU; use them unless the
         // pixel count pads badly (small-M launches) - then 256x128

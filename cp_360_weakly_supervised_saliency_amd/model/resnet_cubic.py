@@ -23,6 +23,9 @@ from .cube_pad import CubePad
 
 __all__ = ['ResNet', 'Bottleneck', 'resnet50']
 
+# A/B switch (tools, tests): False runs the downsample branch as its own convolution + residual add
+FUSE_DOWNSAMPLE = True
+
 
 
 def _fold_bn(bn):
@@ -72,11 +75,19 @@ class Bottleneck(nn.Module):
             plan = {
                 'c1': ops.Conv(self.conv1.weight, s1, b1, 1, 0, True, dt, dev),
                 'c2': ops.Conv(self.conv2.weight, s2, b2, self.stride, 1, True, dt, dev),   # CubePad(1) fused
-                'c3': ops.Conv(self.conv3.weight, s3, b3, 1, 0, True, dt, dev),             # relu after the add
             }
-            if self.downsample is not None:
+            if self.downsample is not None and FUSE_DOWNSAMPLE:
+                # downsample (1x1 conv, stride, + BN on the block input, resnet_cubic.py:99-104) as conv3's
+                # second source: relu(W3.mid + Wd.x + b3 + bd) in one tile, the [M, 4*planes] residual tensor
+                # never exists in HBM
                 sd, bd = _fold_bn(self.downsample[1])
-                plan['ds'] = ops.Conv(self.downsample[0].weight, sd, bd, self.stride, 0, False, dt, dev)
+                plan['c3'] = ops.Conv(self.conv3.weight, s3, b3, 1, 0, True, dt, dev,
+                                      second=(self.downsample[0].weight, sd, bd, self.stride))
+            else:
+                plan['c3'] = ops.Conv(self.conv3.weight, s3, b3, 1, 0, True, dt, dev)       # relu after the add
+                if self.downsample is not None:
+                    sd, bd = _fold_bn(self.downsample[1])
+                    plan['ds'] = ops.Conv(self.downsample[0].weight, sd, bd, self.stride, 0, False, dt, dev)
             self._plan, self._plan_stamp = plan, stamp
         return self._plan
 
@@ -84,6 +95,8 @@ class Bottleneck(nn.Module):
         p = self._plans()
         out = p['c1'](x)
         out = p['c2'](out)
+        if p['c3'].second is not None:
+            return p['c3'](out, x2=x)              # conv3 + bn3 + downsample(x) + relu in one tile
         res = p['ds'](x) if 'ds' in p else x
         return p['c3'](out, residual=res)          # conv3 + bn3 + residual + relu in one epilogue
 

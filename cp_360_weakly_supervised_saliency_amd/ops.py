@@ -187,7 +187,7 @@ class Conv:
     """
 
     def __init__(self, weight, scale=None, bias=None, stride=1, pad=0, relu=False, dtype=torch.float32,
-                 device='cuda', stem=False, clip_resident=None):
+                 device='cuda', stem=False, clip_resident=None, second=None):
         self.dtype = dtype
         self.device = torch.device(device)
         self.stride = int(stride)
@@ -211,6 +211,22 @@ class Conv:
             clip_resident = (not stem and self.pad == 1 and self.stride == 1 and self.kh == 3 and self.kw == 3
                              and self.c_out >= 256)
         self.clip_resident_ok = bool(clip_resident)
+        # second source (cp360_conv_desc.c_in2): (weight2 [c_out, c_in2, 1, 1], scale2, bias2, stride2) - a 1x1
+        # convolution of a SECOND tensor accumulated into the same tile (the Bottleneck's downsample branch
+        # inside conv3); its bias is folded into this conv's bias
+        self.second = None
+        if second is not None:
+            w2, s2, b2, st2 = second
+            if stem or self.c_out < 256 or w2.shape[0] != self.c_out or tuple(w2.shape[2:]) != (1, 1):
+                raise ValueError("a second source needs c_out >= 256 and a [c_out, c_in2, 1, 1] filter")
+            self.second = (w2.detach(), None if s2 is None else s2.detach().to(device=self.device, dtype=torch.float32).contiguous(),
+                           int(st2))
+            self.c_in2 = int(w2.shape[1])
+            if b2 is not None:
+                b2 = b2.detach().to(device=self.device, dtype=torch.float32)
+                self.bias = b2.contiguous() if self.bias is None else (self.bias + b2).contiguous()
+            clip_resident = False
+            self.clip_resident_ok = False
         self._packed = {}
         self._stem_packed = None                # resident-patch stem kernel (16-bit types, cube 224), on first use
         self._band_packed = None                # resident-band 3x3 kernel (64 -> 64 on 56x56 faces), on first use
@@ -228,8 +244,13 @@ class Conv:
                 raise ValueError("unsupported convolution geometry for libcp360")
             w = self._w_src.to(device=self.device, dtype=torch.float32).contiguous()
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            check(lib().cp360_conv_pack_weights(C.byref(d), ptr(w), ptr(self._scale), ptr(t), 1 if self.stem else 0,
-                                                stream()))
+            if self.second is not None:
+                w2 = self.second[0].to(device=self.device, dtype=torch.float32).reshape(self.c_out, self.c_in2).contiguous()
+                check(lib().cp360_conv_pack_weights2(C.byref(d), ptr(w), ptr(self._scale), ptr(w2), ptr(self.second[1]),
+                                                     ptr(t), stream()))
+            else:
+                check(lib().cp360_conv_pack_weights(C.byref(d), ptr(w), ptr(self._scale), ptr(t), 1 if self.stem else 0,
+                                                    stream()))
             self._packed[clip_resident] = t
         return t
 
@@ -243,7 +264,7 @@ class Conv:
                ((w_in + p2 - self.kw_w) // self.stride + 1 if self.stem else (w_in + p2 - self.kw) // self.stride + 1)
 
     def _desc(self, n_img, h_in, w_in, splits, ld_out=None, out_coff=0, ld_res=0, relu=None, tile_px=0,
-              clip_resident=0, slab_rows=0):
+              clip_resident=0, slab_rows=0, x2_shape=None):
         d = ConvDesc()
         d.dtype = dtype_code(self.dtype)
         d.n_img, d.h_in, d.w_in = n_img, h_in, w_in
@@ -259,6 +280,14 @@ class Conv:
         d.tile_px = tile_px
         d.clip_resident = clip_resident
         d.slab_rows = slab_rows
+        if self.second is not None:
+            st2 = self.second[2]
+            d.c_in2 = self.c_in2
+            d.sy2 = d.sx2 = st2
+            if x2_shape is None:                     # packing: any consistent geometry (the layout does not depend on it)
+                d.h_in2, d.w_in2, d.pix_stride2 = (d.h_out - 1) * st2 + 1, (d.w_out - 1) * st2 + 1, self.c_in2
+            else:
+                d.h_in2, d.w_in2, d.pix_stride2 = x2_shape[1], x2_shape[2], x2_shape[3]
         return d
 
     def _stem_resident(self, xp):
@@ -295,13 +324,15 @@ class Conv:
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
 
     def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None,
-                 tile_px=0, clip_resident=None, slab_rows=False):
+                 tile_px=0, clip_resident=None, slab_rows=False, x2=None):
         """x [n_img, h, w, c] NHWC (for the stem: the materialised CubePad(3) output
         [n_img, h+6, w+6, 4]).  Returns [n_img, h_out, w_out, c_out] in self.dtype, or
         with raw_f32=True the (partial [splits, M, c_out] f32, splits) pair whose
         reduction / bias / activation the caller finishes (cp360_lstm_gates, CAM)."""
-        require_gpu(x, residual, out)
+        require_gpu(x, residual, out, x2)
         n_img, h_in, w_in, cx = x.shape
+        if (x2 is not None) != (self.second is not None):
+            raise ValueError("x2 goes with a conv built with second=...")
         if (self.stem and h_in == 230 and w_in == 230 and cx == 4 and residual is None and out is None and not raw_f32
                 and splits is None and tile_px == 0 and self.dtype in (torch.bfloat16, torch.float16)
                 and x.dtype == self.dtype):
@@ -320,6 +351,14 @@ class Conv:
         h_out, w_out = self.out_hw(h_in, w_in)
         M = n_img * h_out * w_out
         x = x.contiguous()
+        x2s = None
+        if x2 is not None:
+            st2 = self.second[2]
+            if x2.dtype != self.dtype or not x2.is_contiguous() or x2.dim() != 4 or x2.shape[0] != n_img \
+                    or x2.shape[3] < self.c_in2 or (h_out - 1) * st2 >= x2.shape[1] or (w_out - 1) * st2 >= x2.shape[2]:
+                raise ValueError("x2 must be a contiguous %s [n_img, >=%d, >=%d, >=%d] tensor"
+                                 % (self.dtype, (h_out - 1) * st2 + 1, (w_out - 1) * st2 + 1, self.c_in2))
+            x2s = tuple(x2.shape)
         _check_buf('out', out, self.dtype, (n_img, h_out, w_out, self.c_out + out_coff))
         _check_buf('residual', residual, self.dtype, (n_img, h_out, w_out, self.c_out))
         ld_out = self.c_out if out is None else out.shape[3]
@@ -334,7 +373,7 @@ class Conv:
             key = (n_img, h_in, w_in, cr)
             splits = self._splits_cache.get(key)
             if splits is None:
-                splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1, clip_resident=cr)))
+                splits = L.cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1, clip_resident=cr, x2_shape=x2s)))
                 self._splits_cache[key] = splits
         # split-K slabs read back by cp360_conv_finish (or, on request, by cp360_lstm_gates) keep the packed
         # row order: contiguous 64-byte stores (cp360_conv_desc.slab_rows)
@@ -342,9 +381,11 @@ class Conv:
         if raw_f32 and slab_rows and not sr:
             raise ValueError("slab_rows needs c_out % 32 == 0")
         d = self._desc(n_img, h_in, w_in, splits, ld_out, out_coff, ld_res, tile_px=tile_px, clip_resident=cr,
-                       slab_rows=sr)
+                       slab_rows=sr, x2_shape=x2s)
         packed = self.packed_for(cr)
         def forward(*a):
+            if x2 is not None:                       # (desc, in, in2, packed, ...)
+                return L.cp360_conv_forward2(a[0], a[1], ptr(x2), *a[2:])
             if LAUNCH_TIMER is None:
                 return L.cp360_conv_forward(*a)
             flops = 2.0 * M * self.c_out * self.c_in_w * self.kh_w * self.kw_w

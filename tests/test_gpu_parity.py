@@ -214,6 +214,59 @@ def test_conv_matches_torch_cpu(case, prec):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('geom', [(64, 64, 256, 14, 1, 0), (96, 200, 264, 14, 2, 0), (128, 256, 512, 10, 2, 304),
+                                  (512, 1024, 2048, 7, 1, 256), (64, 64, 256, 9, 1, 3)])
+def test_conv_second_source_downsample_fused(prec, geom):
+    """cp360_conv_desc.c_in2: out = relu(W3 . mid + b3 + Wd . x[::s, ::s] + bd) in one tile = conv3 + bn3 +
+    downsample(conv1x1 stride s + bn) + add + relu of a Bottleneck's first block (resnet_cubic.py:85-106),
+    against torch-CPU on identically rounded operands.  Last geometry field: forced tile / 3 = split-K 3."""
+    cmid, cin2, cout, n, st, force = geom
+    dt = _TDT[prec]
+    n_img = 6
+    n2 = n * st
+    mid = hashrng.normal(9400, (n_img, cmid, n, n))
+    x = hashrng.normal(9401, (n_img, cin2, n2, n2))
+    w3 = hashrng.normal(9402, (cout, cmid, 1, 1), 0, (2.0 / cmid) ** 0.5)
+    wd = hashrng.normal(9403, (cout, cin2, 1, 1), 0, (2.0 / cin2) ** 0.5)
+    s3, sd = hashrng.uniform(9404, (cout,), 0.5, 1.5), hashrng.uniform(9405, (cout,), 0.5, 1.5)
+    b3, bd = hashrng.normal(9406, (cout,), 0, 0.1), hashrng.normal(9407, (cout,), 0, 0.1)
+    rb = (lambda a: torch.from_numpy(a).to(dt).float().numpy()) if prec != 'fp32' else (lambda a: a)
+    fold = lambda w, sc: rb((torch.from_numpy(w) * torch.from_numpy(sc)[:, None, None, None]).numpy())
+    import torch.nn.functional as Fn
+    with torch.no_grad():
+        want = Fn.conv2d(torch.from_numpy(rb(mid)), torch.from_numpy(fold(w3, s3)), torch.from_numpy(b3)) + \
+            Fn.conv2d(torch.from_numpy(rb(x)), torch.from_numpy(fold(wd, sd)), torch.from_numpy(bd), stride=st)
+        want = torch.relu(want).numpy()
+    conv = ops.Conv(torch.from_numpy(w3), torch.from_numpy(s3), torch.from_numpy(b3), 1, 0, True, dt, DEV,
+                    second=(torch.from_numpy(wd), torch.from_numpy(sd), torch.from_numpy(bd), st))
+    mt = ops.nchw_to_nhwc(torch.from_numpy(mid).to(DEV), out_dtype=dt)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    kw = {'splits': 3} if force == 3 else ({'tile_px': force} if force else {})
+    got = ops.nhwc_to_nchw(conv(mt, x2=xt, **kw), out_dtype=torch.float32).cpu().numpy()
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
+    with pytest.raises(ValueError):
+        conv(mt)                                         # x2 is mandatory for a conv built with second=
+
+
+def test_resnet_fused_downsample_equals_separate(golden_dir):
+    """The whole ResNet with the downsample branches fused into conv3 (default) vs run as separate
+    convolutions + residual add: same f32 result up to summation order."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    x = torch.from_numpy(hashrng.normal(4000 + 64, (6, 64, 64, 3), 0.0, 1.0)).to(DEV)
+    x4 = ops.cubepad_nhwc(x, 0, c_out=4)
+    outs = []
+    for fuse in (True, False):
+        rc.FUSE_DOWNSAMPLE = fuse
+        try:
+            m, _ = _load_resnet()
+            outs.append(m.features_nhwc(x4).float().cpu().numpy())
+        finally:
+            rc.FUSE_DOWNSAMPLE = True
+    assert rel_err(outs[0], outs[1]) <= 2e-5
+
+
 @pytest.mark.parametrize('tile_px', [128, 256, 304])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('splits', [1, 3])
