@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 201
+ABI_VERSION = 202
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -37,6 +37,7 @@ SYMBOLS = [
     'cp360_conv_finish',
     'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_window_minmax',
     'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes', 'cp360_band3x3_pack_weights', 'cp360_band3x3_forward',
+    'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1', 'cp360_l1block_forward',
 ]
 
 
@@ -103,6 +104,10 @@ def lib():
     L.cp360_band3x3_packed_bytes.argtypes = [i]
     L.cp360_band3x3_pack_weights.argtypes = [i, vp, vp, vp, vp]
     L.cp360_band3x3_forward.argtypes = [i, vp, vp, vp, vp, i, i, i, i, vp]
+    L.cp360_frag_packed_bytes.restype = sz
+    L.cp360_frag_packed_bytes.argtypes = [i, i, i]
+    L.cp360_frag_pack_1x1.argtypes = [i, vp, vp, vp, i, i, i, vp]
+    L.cp360_l1block_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):

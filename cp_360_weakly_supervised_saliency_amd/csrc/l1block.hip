@@ -1,0 +1,426 @@
+// K3d: one whole Bottleneck tail of layer1 in ONE kernel (16-bit types, 56x56 cube faces):
+//
+//   mid  --CubePad(1)+conv3x3 64->64 +bn2+relu-->  t  --conv1x1 64->256 +bn3 (+ residual | + downsample(x)) +relu-->  out
+//                                                        `--(optional) next block's conv1x1 256->64 +bn1+relu-->  mid'
+//
+// = conv2 / conv3 / residual add of model/resnet_cubic.py:85-106 and the conv1 of the NEXT block (:88-90).
+// Run as separate launches these are HBM-bound (layer1 = 1.9 of the static stage's 7 ms) and every
+// tensor between them makes a round trip through HBM: t (154 MB for 64 frames) twice, out (616 MB) written by conv3
+// and read again by the next conv1.  Here a workgroup owns a band of 4 output rows of one face, as band3x3.hip:
+//   stage 1  conv2 exactly as band3x3_kernel (resident cube-padded band in LDS, nine taps read it there);
+//   stage 2  the conv2 accumulators ARE the next MFMA's B operand: with the acc_chan row order of the packed
+//            weights a lane ends with EIGHT consecutive channels of one pixel per pair of MFMA row blocks - the
+//            k-group layout of a 16x16x32 B fragment.  bias + ReLU + one rounding and the packed 16 bytes feed conv3
+//            straight from registers (no LDS round trip, no barrier);
+//   stage 3  conv3 in 8 passes of 32 output channels (K = 64: 16 MFMAs per pass and wave); its epilogue adds the
+//            residual piece (16-byte loads, 64 contiguous bytes per pixel and pass) or, for the first block, the
+//            downsample branch as 16 more MFMAs on x's fragments (K = 64 + 64), applies ReLU, rounds once, stores
+//            the 16-byte piece - and that packed piece is again a B fragment: k-block `pass` of the next block's
+//            conv1, accumulated on the fly (16 MFMAs per pass).
+// conv3's (and the next conv1's) weights sit in LDS in fragment order (the conv2 ring and the patch are dead by
+// then), the downsample filter's fragments come from L2.  Wave w = output row w of the band, as in stage 1.
+// HBM traffic per block (64 frames): mid 154 MB + residual 616 MB + out 616 MB (+ mid' 154 MB) instead of
+// 154 + 154 | 154 + 616 + 616 | 616 + 154.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+constexpr int N = 56, NP = N + 2, C = 64, CO = 256, BAND = 4;
+constexpr int PATCH_PX = (BAND + 2) * NP;                    // 348
+constexpr int PATCH_INST = (PATCH_PX + 7) / 8;               // 44 DMA instructions of 8 pixels x 128 B
+constexpr int PATCH_LDS = PATCH_INST * 1024;                 // 45,056
+constexpr int W_TAP = 64 * 128;                              // 8 KiB: one tap's 64 rows x 64 channels
+constexpr int W_SLOTS = 3;
+constexpr int LDS_BYTES = PATCH_LDS + W_SLOTS * W_TAP;       // 69,632: two workgroups per CU
+constexpr int W3_BYTES = CO * C * 2;                         // 32 KiB of conv3 fragments
+constexpr int W1_BYTES = C * CO * 2;                         // 32 KiB of next-conv1 fragments
+static_assert(W3_BYTES + W1_BYTES <= LDS_BYTES, "stage-3 weights must fit the LDS of stage 1");
+
+__device__ __attribute__((aligned(16))) unsigned int l_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ int px_swz(int p) { return ((p >> 1) & 3) << 1; }
+__device__ __forceinline__ int w_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma<bf16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<f16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], bf16_raw) {
+    u32x4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3],
+                      (f16_raw)v[4], (f16_raw)v[5], (f16_raw)v[6], (f16_raw)v[7]};
+    return __builtin_bit_cast(u32x4, h);
+}
+__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], bf16_raw) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = __builtin_bit_cast(f16x8v, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+}
+// packed row R of a 32-row group <- channel (acc_chan order: MFMA blocks 2q, 2q+1 give a lane 8 consecutive channels)
+__host__ __device__ __forceinline__ int row_chan(int R) { return (R & ~31) + ((R >> 2) & 3) * 8 + ((R >> 4) & 1) * 4 + (R & 3); }
+}  // namespace
+
+// 1x1 filter w [n_out, k] (times scale[n_out]) -> MFMA A fragments, 1 KiB each ([lane][8 elements]: lane l holds
+// row (l & 15), k-group (l >> 4) of the fragment), rows in acc_chan order.
+//   order 0 (row-pair major, for conv3 / downsample):  fragment ((p * 2 + rb) * KB + kb), p = 32-row pair
+//   order 1 (k major, for the chained next conv1):     fragment (kb * RB + rb), rb = 16-row block
+template <typename T>
+__global__ __launch_bounds__(256) void frag_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                        T* __restrict__ packed, int n_out, int k, int order) {
+    const int KB = k / 32, RB = n_out / 16;
+    const int total = n_out * k;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, frag = idx >> 9;
+        int rb, kb;
+        if (order == 0) { kb = frag % KB; rb = frag / KB; }
+        else            { rb = frag % RB; kb = frag / RB; }
+        const int R = rb * 16 + (lane & 15);
+        const int n = row_chan(R);
+        const int kk = kb * 32 + (lane >> 4) * 8 + e;
+        const float v = w[(size_t)n * k + kk] * (scale ? scale[n] : 1.f);
+        if constexpr (__is_same(T, f16_raw)) packed[idx] = (f16_raw)v;
+        else packed[idx] = f32_to_bf16(v);
+    }
+}
+
+template <typename T, bool DS, bool NEXT>
+__global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
+                                                         const float* __restrict__ bias2, const T* __restrict__ w3f,
+                                                         const float* __restrict__ bias3, const T* __restrict__ res,
+                                                         const T* __restrict__ xds, const T* __restrict__ wdf,
+                                                         T* __restrict__ out, const T* __restrict__ w1f,
+                                                         const float* __restrict__ bias1, T* __restrict__ out_next) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int tile = blockIdx.x, img = tile / (N / BAND), band = tile - img * (N / BAND);
+    const int grp = img / 6, f = img - grp * 6;
+    const CubePadGeom geom{N, 1, 1, 1, 1};
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    const size_t row_px = ((size_t)img * N + band * BAND + wave) * N;     // first pixel of this wave's output row
+
+    // ---- stage 1: conv2 on the resident cube-padded band (band3x3.hip)
+    {
+        const T* xg = x + (size_t)grp * 6 * N * N * C;
+#pragma unroll 1
+        for (int inst = wave; inst < PATCH_INST; inst += 4) {
+            const int q = inst * 8 + (lane >> 3);
+            const void* src = l_zero16;
+            if (q < PATCH_PX) {
+                const int pr = q / NP, pc = q - pr * NP;
+                const int sp = cubepad_src(f, BAND * band + pr, pc, geom);
+                src = xg + (size_t)sp * C + (((lane & 7) ^ px_swz(q)) << 3);
+            }
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+        }
+    }
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk2);
+    auto load_w = [&](int t, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int inst = wave * 2 + q;
+            const int row = inst * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            glds16(wb + (size_t)t * W_TAP + row * 128 + chunk * 16,
+                   __builtin_amdgcn_readfirstlane(lds_base + PATCH_LDS + s * W_TAP + inst * 1024));
+        }
+    };
+    load_w(0, 0);
+    load_w(1, 1);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tap + 2 < 9) load_w(tap + 2, (tap + 2) % W_SLOTS);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const unsigned char* Ws = lds + PATCH_LDS + (tap % W_SLOTS) * W_TAP;
+        const int pbase = (wave + ky) * NP + kx + lrow;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(Ws + w_off(i * 16 + lrow, kk * 4 + lchunk));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = pbase + 16 * j;
+                b[j] = *reinterpret_cast<const u32x4*>(lds + p * 128 + (((kk * 4 + lchunk) ^ px_swz(p)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], a[i], b[j]);
+        }
+    }
+    // every wave is done with the patch and the weight ring: bring conv3's (and the next conv1's) fragments in
+    __syncthreads();
+    {
+        const unsigned char* s3 = reinterpret_cast<const unsigned char*>(w3f);
+#pragma unroll
+        for (int q = 0; q < W3_BYTES / 1024 / 4; ++q) {
+            const int inst = q * 4 + wave;
+            glds16(s3 + inst * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+        }
+        if (NEXT) {
+            const unsigned char* s1 = reinterpret_cast<const unsigned char*>(w1f);
+#pragma unroll
+            for (int q = 0; q < W1_BYTES / 1024 / 4; ++q) {
+                const int inst = q * 4 + wave;
+                glds16(s1 + inst * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_base + W3_BYTES + inst * 1024));
+            }
+        }
+    }
+    // ---- stage 2: t = relu(conv2 + b2), rounded once, as B fragments bt[k-block][pixel block]
+    u32x4 bt[2][4];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const int n = pr * 32 + lchunk * 8;
+        float bb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[e] = bias2 ? bias2[n + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(acc[2 * pr][j][e] + bb[e], 0.f);
+                v[4 + e] = fmaxf(acc[2 * pr + 1][j][e] + bb[4 + e], 0.f);
+            }
+            bt[pr][j] = pack8(v, T());
+        }
+    }
+    // downsample source: x's fragments of this wave's pixels (k-block kb = channels 32 kb .. +31)
+    u32x4 bx[2][4];
+    if (DS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xo = j * 16 + lrow;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const T* src = xo < N ? xds + (row_px + xo) * C + kb * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
+                bx[kb][j] = *reinterpret_cast<const u32x4*>(src);
+            }
+        }
+    }
+    // acc (stage 1) is dead: the same registers hold the next conv1's accumulators
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_res = [&](int p, u32x4 (&r)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xo = j * 16 + lrow;
+            const T* src = xo < N ? res + (row_px + xo) * CO + p * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
+            r[j] = *reinterpret_cast<const u32x4*>(src);
+        }
+    };
+    u32x4 r[4];
+    if (!DS) load_res(0, r);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the fragment DMAs (and the first residual pieces)
+    __syncthreads();
+
+    // ---- stage 3: conv3 in 8 passes of 32 channels (+ residual | downsample) -> out, chained next conv1
+    const unsigned char* W3s = lds;
+    const unsigned char* W1s = lds + W3_BYTES;
+#pragma unroll 1
+    for (int p = 0; p < 8; ++p) {
+        u32x4 rn[4];
+        if (!DS && p < 7) load_res(p + 1, rn);
+        u32x4 ad[2][2];
+        if (DS) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    ad[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wdf) +
+                                                                 (((p * 2 + rb) * 2 + kb) * 64 + lane) * 16);
+        }
+        u32x4 a3[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                a3[rb][kb] = *reinterpret_cast<const u32x4*>(W3s + (((p * 2 + rb) * 2 + kb) * 64 + lane) * 16);
+        f32x4 c3[2][4];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c3[rb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma<T>(c3[rb][j], a3[rb][kb], bt[kb][j]);
+        if (DS) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma<T>(c3[rb][j], ad[rb][kb], bx[kb][j]);
+        }
+        const int n = p * 32 + lchunk * 8;
+        float bb[8];
+        {
+            const float4 t0 = *reinterpret_cast<const float4*>(bias3 + n);
+            const float4 t1 = *reinterpret_cast<const float4*>(bias3 + n + 4);
+            bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
+        }
+        u32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = c3[0][j][e] + bb[e];
+                v[4 + e] = c3[1][j][e] + bb[4 + e];
+            }
+            if (!DS) {
+                float rv[8];
+                unpack8(r[j], rv, T());
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            o[j] = pack8(v, T());
+            const int xo = j * 16 + lrow;
+            if (xo < N) *reinterpret_cast<u32x4*>(out + (row_px + xo) * CO + n) = o[j];
+        }
+        if (NEXT) {     // out's channels 32p .. 32p+31 = k-block p of the next conv1
+            u32x4 a1[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                a1[rb] = *reinterpret_cast<const u32x4*>(W1s + ((p * 4 + rb) * 64 + lane) * 16);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma<T>(acc[rb][j], a1[rb], o[j]);
+        }
+        if (!DS && p < 7) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = rn[j];
+        }
+    }
+    if (NEXT) {
+        T* orow = out_next + row_px * C;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n = pr * 32 + lchunk * 8;
+            float bb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = bias1 ? bias1[n + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xo = j * 16 + lrow;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[2 * pr][j][e] + bb[e], 0.f);
+                    v[4 + e] = fmaxf(acc[2 * pr + 1][j][e] + bb[4 + e], 0.f);
+                }
+                if (xo < N) *reinterpret_cast<u32x4*>(orow + (size_t)xo * C + n) = pack8(v, T());
+            }
+        }
+    }
+}
+
+extern "C" size_t cp360_frag_packed_bytes(int dtype, int n_out, int k) {
+    if ((dtype != CP360_BF16 && dtype != CP360_F16) || n_out <= 0 || k <= 0 || n_out % 32 != 0 || k % 32 != 0) return 0;
+    return (size_t)n_out * k * 2;
+}
+
+extern "C" int cp360_frag_pack_1x1(int dtype, const float* w, const float* scale, void* packed, int n_out, int k,
+                                   int order, void* stream) {
+    if (!w || !packed) return CP360_ERR_NULL;
+    if (n_out <= 0 || k <= 0 || n_out % 32 != 0 || k % 32 != 0 || (order != 0 && order != 1)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((n_out * k + 255) / 256);
+    if (dtype == CP360_BF16)
+        hipLaunchKernelGGL((frag_pack_kernel<bf16_raw>), dim3(blocks), dim3(256), 0, st, w, scale, (bf16_raw*)packed, n_out, k, order);
+    else if (dtype == CP360_F16)
+        hipLaunchKernelGGL((frag_pack_kernel<f16_raw>), dim3(blocks), dim3(256), 0, st, w, scale, (f16_raw*)packed, n_out, k, order);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                                     const void* w3_frags, const float* bias3, const void* residual, const void* x_ds,
+                                     const void* wd_frags, void* out, const void* w1_frags, const float* bias1,
+                                     void* out_next, int n_img, int face, void* stream) {
+    if (!mid || !w2_packed || !w3_frags || !bias3 || !out) return CP360_ERR_NULL;
+    if ((residual != nullptr) == (x_ds != nullptr)) return CP360_ERR_NULL;        // exactly one of the two
+    if (x_ds && !wd_frags) return CP360_ERR_NULL;
+    if ((w1_frags != nullptr) != (out_next != nullptr)) return CP360_ERR_NULL;
+    if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
+    if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+    if (face != N) return CP360_ERR_UNSUPPORTED;                                  // other sizes: the per-convolution path
+    if ((long long)n_img * N * N * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)(n_img * (N / BAND)));
+#define CP360_L1B(TT, DSV, NX)                                                                                  \
+    hipLaunchKernelGGL((l1block_kernel<TT, DSV, NX>), grid, dim3(256), 0, st, (const TT*)mid, (const TT*)w2_packed, \
+                       bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (const TT*)x_ds, (const TT*)wd_frags, \
+                       (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next)
+#define CP360_L1B_T(TT)                                         \
+    {                                                           \
+        if (x_ds && w1_frags) CP360_L1B(TT, true, true);        \
+        else if (x_ds) CP360_L1B(TT, true, false);              \
+        else if (w1_frags) CP360_L1B(TT, false, true);          \
+        else CP360_L1B(TT, false, false);                       \
+    }
+    if (dtype == CP360_BF16) CP360_L1B_T(bf16_raw)
+    else if (dtype == CP360_F16) CP360_L1B_T(f16_raw)
+    else return CP360_ERR_BAD_DTYPE;
+#undef CP360_L1B_T
+#undef CP360_L1B
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

@@ -25,6 +25,7 @@ __all__ = ['ResNet', 'Bottleneck', 'resnet50']
 
 # A/B switch (tools, tests): False runs the downsample branch as its own convolution + residual add
 FUSE_DOWNSAMPLE = True
+FUSE_LAYER1 = True
 
 
 
@@ -192,10 +193,45 @@ class ResNet(nn.Module):
         x = self._stem_conv()(xp)
         return ops.cubepad_maxpool3s2(x)
 
+    def _layer1_fused(self):
+        """ops.L1Block per Bottleneck of layer1 (K3d), rebuilt when a parameter changes."""
+        dt = _DTYPES[self.precision]
+        stamp = _stamp(self.layer1, (self.precision,))
+        if getattr(self, '_l1', None) is None or stamp != self._l1_stamp:
+            dev = self.conv1.weight.device
+            blks = list(self.layer1)
+            out = []
+            for k, b in enumerate(blks):
+                c = lambda conv, bn: (conv.weight,) + _fold_bn(bn)
+                nxt = c(blks[k + 1].conv1, blks[k + 1].bn1) if k + 1 < len(blks) else None
+                ds = c(b.downsample[0], b.downsample[1]) if b.downsample is not None else None
+                out.append(ops.L1Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), ds, nxt, dt, dev))
+            self._l1, self._l1_stamp = out, stamp
+        return self._l1
+
+    def layer1_nhwc(self, x):
+        """layer1 on the fused path.  16-bit types at 56x56 faces: conv1 of the first block, then ONE launch per
+        Bottleneck (conv2 -> conv3 + residual / downsample -> the next block's conv1, csrc/l1block.hip)."""
+        dt = _DTYPES[self.precision]
+        blks = list(self.layer1)
+        if not (FUSE_LAYER1 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == 56 and x.shape[2] == 56
+                and blks[0].stride == 1 and blks[0].downsample is not None
+                and all(b.downsample is None for b in blks[1:])):
+            for blk in blks:
+                x = blk.forward_nhwc(x)
+            return x
+        fused = self._layer1_fused()
+        mid = blks[0]._plans()['c1'](x)
+        out, mid = fused[0](mid, x_ds=x)
+        for k in range(1, len(blks)):
+            out, mid = fused[k](mid, residual=out)
+        return out
+
     def features_nhwc(self, x_nhwc4, padded=False):
         """Fused path to layer4: [6N, H, W, 4] -> [6N, H/32, W/32, 2048]."""
         x = self.stem_nhwc(x_nhwc4, padded)
-        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+        x = self.layer1_nhwc(x)
+        for layer in (self.layer2, self.layer3, self.layer4):
             for blk in layer:
                 x = blk.forward_nhwc(x)
         return x

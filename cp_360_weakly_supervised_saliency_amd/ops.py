@@ -417,6 +417,76 @@ class Conv:
         return out
 
 
+def frag_pack_1x1(weight, scale, dtype, order, device):
+    """1x1 filter [n_out, k(, 1, 1)] (f32) times scale[n_out] -> MFMA A fragments (cp360_frag_pack_1x1)."""
+    n_out, k = int(weight.shape[0]), int(weight.shape[1])
+    code = dtype_code(dtype)
+    nbytes = lib().cp360_frag_packed_bytes(code, n_out, k)
+    if nbytes == 0:
+        raise ValueError("fragment packing needs a 16-bit type and n_out, k multiples of 32")
+    w = weight.detach().to(device=device, dtype=torch.float32).reshape(n_out, k).contiguous()
+    sc = None if scale is None else scale.detach().to(device=device, dtype=torch.float32).contiguous()
+    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    check(lib().cp360_frag_pack_1x1(code, ptr(w), ptr(sc), ptr(t), n_out, k, int(order), stream()))
+    return t
+
+
+class L1Block:
+    """K3d (csrc/l1block.hip): one layer1 Bottleneck after its conv1 as ONE launch - conv2 + bn2 + relu ->
+    conv3 + bn3 + (residual | downsample(x)) + relu -> optionally the next block's conv1 + bn1 + relu.
+    16-bit types, 56x56 faces.  Arguments: (weight, bn scale, bn bias) triples of the convolutions."""
+
+    def __init__(self, conv2, conv3, downsample=None, next_conv1=None, dtype=torch.float16, device='cuda'):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("L1Block runs in fp16 / bf16")
+        self.dtype, self.device = dtype, torch.device(device)
+        L, code = lib(), dtype_code(dtype)
+        f32 = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        w2, s2, b2 = conv2
+        if tuple(w2.shape) != (64, 64, 3, 3) or tuple(conv3[0].shape[:2]) != (256, 64):
+            raise ValueError("L1Block is layer1's geometry: conv2 64->64 3x3, conv3 64->256 1x1")
+        self.w2 = torch.empty(L.cp360_band3x3_packed_bytes(code), dtype=torch.uint8, device=self.device)
+        check(L.cp360_band3x3_pack_weights(code, ptr(f32(w2)), ptr(f32(s2)), ptr(self.w2), stream()))
+        self.b2 = f32(b2)
+        w3, s3, b3 = conv3
+        self.w3 = frag_pack_1x1(w3, s3, dtype, 0, self.device)
+        self.b3 = f32(b3)
+        self.wd = None
+        if downsample is not None:
+            wd, sd, bd = downsample
+            if tuple(wd.shape[:2]) != (256, 64):
+                raise ValueError("layer1's downsample is 64->256, stride 1")
+            self.wd = frag_pack_1x1(wd, sd, dtype, 0, self.device)
+            self.b3 = (self.b3 + f32(bd)).contiguous()
+        self.w1 = self.b1 = None
+        if next_conv1 is not None:
+            w1, s1, b1 = next_conv1
+            if tuple(w1.shape[:2]) != (64, 256):
+                raise ValueError("the chained conv1 is 256->64")
+            self.w1 = frag_pack_1x1(w1, s1, dtype, 1, self.device)
+            self.b1 = f32(b1)
+
+    def __call__(self, mid, residual=None, x_ds=None):
+        """mid [n_img, 56, 56, 64]; residual [n_img, 56, 56, 256] (identity blocks) or x_ds [n_img, 56, 56, 64]
+        (the first block).  Returns (out [n_img, 56, 56, 256], next conv1's output [n_img, 56, 56, 64] or None)."""
+        require_gpu(mid, residual, x_ds)
+        if (self.wd is None) != (x_ds is None) or (residual is None) == (x_ds is None):
+            raise ValueError("identity blocks take residual=, the downsample block takes x_ds=")
+        n_img = mid.shape[0]
+        _check_buf('mid', mid, self.dtype, (n_img, 56, 56, 64))
+        _check_buf('residual', residual, self.dtype, (n_img, 56, 56, 256))
+        _check_buf('x_ds', x_ds, self.dtype, (n_img, 56, 56, 64))
+        for t in (mid, residual, x_ds):
+            if t is not None and t.shape[3] not in (64, 256):
+                raise ValueError("dense NHWC tensors only")
+        out = torch.empty((n_img, 56, 56, 256), dtype=self.dtype, device=mid.device)
+        nxt = None if self.w1 is None else torch.empty((n_img, 56, 56, 64), dtype=self.dtype, device=mid.device)
+        check(lib().cp360_l1block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
+                                          ptr(self.b3), ptr(residual), ptr(x_ds), ptr(self.wd), ptr(out), ptr(self.w1),
+                                          ptr(self.b1), ptr(nxt), n_img, 56, stream()))
+        return out, nxt
+
+
 def cubepad_maxpool3s2(x):
     """CubePad(1) + MaxPool2d(3, 2, 0) on NHWC (resnet_cubic.py:169-170)."""
     require_gpu(x)

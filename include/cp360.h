@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 201
+#define CP360_VERSION 202
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -256,6 +256,33 @@ int cp360_band3x3_pack_weights(int dtype, const float* w_oihw /* [64,64,3,3] */,
                                void* packed, void* stream);
 int cp360_band3x3_forward(int dtype, const void* x, const void* packed, const float* bias, void* out,
                           int n_img, int face, int channels, int relu, void* stream);
+
+/* ------------------------------------------------------------------ K3d: fused Bottleneck tail (layer1)
+ * One kernel for  conv2 (CubePad(1) + 3x3, 64 -> 64) + bn2 + relu  ->  conv3 (1x1, 64 -> 256) + bn3
+ * + (identity residual | downsample(x) = conv1x1 64 -> 256 + bn) + relu  ->  [optional] the NEXT block's
+ * conv1 (1x1, 256 -> 64) + bn1 + relu : model/resnet_cubic.py:85-106 for the three Bottlenecks of layer1 at
+ * cube size 224 (56x56 faces), CP360_BF16 / CP360_F16 only.  Nothing between the convolutions goes through
+ * HBM: conv2's accumulators feed conv3 from registers, conv3's rounded output feeds the next conv1.
+ *   mid        [n_img, 56, 56, 64]   this block's conv1 output (NHWC)
+ *   w2_packed  cp360_band3x3_pack_weights layout, bias2 f32 [64]
+ *   w3_frags   cp360_frag_pack_1x1(w3 [256, 64], order 0), bias3 f32 [256] (with the downsample branch: b3 + bd)
+ *   residual   [n_img, 56, 56, 256] or NULL;  x_ds [n_img, 56, 56, 64] + wd_frags (order 0, [256, 64]) or NULL:
+ *              exactly one of residual / x_ds
+ *   out        [n_img, 56, 56, 256]
+ *   w1_frags   cp360_frag_pack_1x1(w1_next [64, 256], order 1) + bias1 f32 [64] + out_next [n_img, 56, 56, 64],
+ *              or all NULL
+ * Other face sizes: CP360_ERR_UNSUPPORTED (the per-convolution path handles them).
+ */
+/* MFMA A-fragment packing of a 1x1 filter w [n_out, k] (f32, times scale[n_out] or NULL): 1 KiB fragments of
+ * 16 rows x 32 k, rows in the kernels' acc_chan order; order 0 = row-block major ([n_out/16][k/32]),
+ * order 1 = k-block major ([k/32][n_out/16]).  n_out % 32 == 0, k % 32 == 0. */
+size_t cp360_frag_packed_bytes(int dtype, int n_out, int k);
+int cp360_frag_pack_1x1(int dtype, const float* w, const float* scale, void* packed, int n_out, int k,
+                        int order, void* stream);
+int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                          const void* w3_frags, const float* bias3, const void* residual, const void* x_ds,
+                          const void* wd_frags, void* out, const void* w1_frags, const float* bias1,
+                          void* out_next, int n_img, int face, void* stream);
 
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),

@@ -267,6 +267,35 @@ def test_resnet_fused_downsample_equals_separate(golden_dir):
     assert rel_err(outs[0], outs[1]) <= 2e-5
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n_img', [6, 12])
+def test_layer1_fused_block_kernel(prec, n_img):
+    """K3d (csrc/l1block.hip): layer1 as conv1 + one launch per Bottleneck vs (a) the per-convolution path and
+    (b) torch-CPU on cube-padded input (reference modules' arithmetic, resnet_cubic.py:85-106) - every
+    intermediate is rounded at the same points in all three."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    from oracle import o_resnet
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4500 + n_img, (n_img, 56, 56, 64), 0.0, 1.0))).to(DEV).to(dt)
+    got = m.layer1_nhwc(x).float().cpu().numpy()
+    rc.FUSE_LAYER1 = False
+    try:
+        sep = m.layer1_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_LAYER1 = True
+    assert got.shape == (n_img, 56, 56, 256)
+    assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    # torch-CPU layer1 in f32 from the same (16-bit) input: loose bound, three blocks of 16-bit roundings
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xc = x.float().cpu().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for b in range(3):
+            xc = o_resnet._bottleneck(xc, sdt, 'layer1.%d' % b, 1, b == 0)
+        want = xc.permute(0, 2, 3, 1).numpy()
+    assert rel_err(got, want) <= 4 * _TOL[prec], rel_err(got, want)
+
+
 @pytest.mark.parametrize('tile_px', [128, 256, 304])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('splits', [1, 3])
