@@ -38,7 +38,7 @@ constexpr int W_SLOTS = 3;
 constexpr int LDS_BYTES = PATCH_LDS + W_SLOTS * W_TAP;       // 69,632: two workgroups per CU
 constexpr int W3_BYTES = CO * C * 2;                         // 32 KiB of conv3 fragments
 constexpr int W1_BYTES = C * CO * 2;                         // 32 KiB of next-conv1 fragments
-static_assert(W3_BYTES + W1_BYTES <= LDS_BYTES, "stage-3 weights must fit the LDS of stage 1");
+static_assert(W3_BYTES + W1_BYTES + (CO + C) * 4 <= LDS_BYTES, "stage-3 weights must fit the LDS of stage 1");
 
 __device__ __attribute__((aligned(16))) unsigned int l_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -258,8 +258,28 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
             r[j] = *reinterpret_cast<const u32x4*>(src);
         }
     };
-    u32x4 r[4];
-    if (!DS) load_res(0, r);
+    // residual pieces are requested TWO passes ahead, the downsample filter's fragments one pass ahead (a pass
+    // is ~0.3 us of MFMA work, an HBM / L2 round trip several times that)
+    u32x4 r[4], r1[4];
+    auto load_wd = [&](int p, u32x4 (&a)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                a[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wdf) +
+                                                            (((p * 2 + rb) * 2 + kb) * 64 + lane) * 16);
+    };
+    u32x4 ad[2][2];
+    if (!DS) {
+        load_res(0, r);
+        load_res(1, r1);
+    } else {
+        load_wd(0, ad);
+    }
+    // biases through LDS (the 4 KiB behind the fragments): one ds_read per pass instead of dependent global loads
+    float* bias_s = reinterpret_cast<float*>(lds + W3_BYTES + W1_BYTES);
+    bias_s[tid] = bias3[tid];
+    if (NEXT && tid < C) bias_s[CO + tid] = bias1 ? bias1[tid] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the fragment DMAs (and the first residual pieces)
     __syncthreads();
 
@@ -268,23 +288,17 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     const unsigned char* W1s = lds + W3_BYTES;
 #pragma unroll 1
     for (int p = 0; p < 8; ++p) {
-        u32x4 rn[4];
-        if (!DS && p < 7) load_res(p + 1, rn);
-        u32x4 ad[2][2];
-        if (DS) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    ad[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(wdf) +
-                                                                 (((p * 2 + rb) * 2 + kb) * 64 + lane) * 16);
-        }
+        u32x4 r2[4], adn[2][2];
+        if (!DS && p < 6) load_res(p + 2, r2);
+        if (DS && p < 7) load_wd(p + 1, adn);
         u32x4 a3[2][2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
                 a3[rb][kb] = *reinterpret_cast<const u32x4*>(W3s + (((p * 2 + rb) * 2 + kb) * 64 + lane) * 16);
+        const int n = p * 32 + lchunk * 8;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + n), b1v = *reinterpret_cast<const f32x4*>(bias_s + n + 4);
         f32x4 c3[2][4];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
@@ -304,21 +318,14 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mma<T>(c3[rb][j], ad[rb][kb], bx[kb][j]);
         }
-        const int n = p * 32 + lchunk * 8;
-        float bb[8];
-        {
-            const float4 t0 = *reinterpret_cast<const float4*>(bias3 + n);
-            const float4 t1 = *reinterpret_cast<const float4*>(bias3 + n + 4);
-            bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
-        }
         u32x4 o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = c3[0][j][e] + bb[e];
-                v[4 + e] = c3[1][j][e] + bb[4 + e];
+                v[e] = c3[0][j][e] + b0[e];
+                v[4 + e] = c3[1][j][e] + b1v[e];
             }
             if (!DS) {
                 float rv[8];
@@ -342,9 +349,17 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma<T>(acc[rb][j], a1[rb], o[j]);
         }
-        if (!DS && p < 7) {
+        if (!DS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = rn[j];
+            for (int j = 0; j < 4; ++j) {
+                r[j] = r1[j];
+                r1[j] = r2[j];
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) ad[rb][kb] = adn[rb][kb];
         }
     }
     if (NEXT) {
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
             const int n = pr * 32 + lchunk * 8;
             float bb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bb[e] = bias1 ? bias1[n + e] : 0.f;
+            for (int e = 0; e < 8; ++e) bb[e] = bias_s[CO + n + e];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int xo = j * 16 + lrow;
