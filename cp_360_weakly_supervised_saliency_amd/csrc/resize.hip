@@ -23,20 +23,37 @@ static double lanczos_filter(double x) {
     return 0.0;
 }
 
-extern "C" int cp360_resize_ksize(int in_size, int out_size) {
+// Pillow's bicubic (Image.CUBIC / BICUBIC): Keys kernel with a = -0.5, support 2 (Resample.c: bicubic_filter) -
+// the filter of utils/utils.py:21 (overlay: heatmap.resize(img.size, resample=Image.CUBIC))
+static double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+static double filter_support(int filter) { return filter == 1 ? 2.0 : 3.0; }
+
+extern "C" int cp360_resize_ksize2(int in_size, int out_size, int filter) {
     if (in_size <= 0 || out_size <= 0) return CP360_ERR_BAD_SHAPE;
+    if (filter != 0 && filter != 1) return CP360_ERR_UNSUPPORTED;
     double filterscale = (double)in_size / out_size;
     if (filterscale < 1.0) filterscale = 1.0;
-    return (int)ceil(3.0 * filterscale) * 2 + 1;
+    return (int)ceil(filter_support(filter) * filterscale) * 2 + 1;
 }
+extern "C" int cp360_resize_ksize(int in_size, int out_size) { return cp360_resize_ksize2(in_size, out_size, 0); }
 
 extern "C" int cp360_resize_coeffs_host(int in_size, int out_size, int* bounds, int* kk) {
+    return cp360_resize_coeffs_host2(in_size, out_size, 0, bounds, kk);
+}
+
+extern "C" int cp360_resize_coeffs_host2(int in_size, int out_size, int filter, int* bounds, int* kk) {
     if (!bounds || !kk) return CP360_ERR_NULL;
-    const int ksize = cp360_resize_ksize(in_size, out_size);
+    const int ksize = cp360_resize_ksize2(in_size, out_size, filter);
     if (ksize < 0) return ksize;
     double scale = (double)in_size / out_size, filterscale = scale;
     if (filterscale < 1.0) filterscale = 1.0;
-    const double support = 3.0 * filterscale, ss = 1.0 / filterscale;
+    const double support = filter_support(filter) * filterscale, ss = 1.0 / filterscale;
     double* w = (double*)malloc(sizeof(double) * ksize);
     if (!w) return CP360_ERR_HIP;
     for (int xx = 0; xx < out_size; ++xx) {
@@ -48,7 +65,8 @@ extern "C" int cp360_resize_coeffs_host(int in_size, int out_size, int* bounds, 
         xmax -= xmin;
         double ww = 0.0;
         for (int x = 0; x < xmax; ++x) {
-            w[x] = lanczos_filter((x + xmin - center + 0.5) * ss);
+            const double arg = (x + xmin - center + 0.5) * ss;
+            w[x] = filter == 1 ? bicubic_filter(arg) : lanczos_filter(arg);
             ww += w[x];
         }
         int* k = kk + (size_t)xx * ksize;

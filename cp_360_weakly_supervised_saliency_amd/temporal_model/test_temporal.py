@@ -51,3 +51,35 @@ class ClipRunner:
             cur ^= 1
         sal = self.c2e.saliency(self.h_f32, layout='nhwc')
         return (sal, self.h_f32) if return_hidden else sal
+
+
+def infer_video_dir(cell, c2e, indir, vid_name, output_dir=None, num_subseq=5, max_windows=64):
+    """File-based counterpart of the reference's ``test()`` loop (test_temporal.py:41-88): read the
+    ``<indir>/<vid_name>/cube_feat/*.npy`` files its static stage wrote ([6, C, w, w] float32 per frame),
+    run every stride-1 window of ``num_subseq`` frames through the ConvLSTM on the GPU (``max_windows`` windows per
+    launch group, zero-copy over one feature sequence) and, with ``output_dir``, save each window's map as
+    ``<output_dir>/<vid_name>/{:05}.npy`` named after the window's LAST frame index (:86-88).
+    Returns float32 [n_windows, 2w, 4w] (host).  The reference skips the last window of a sequence
+    (``idx >= len(seq) - num_subseq: continue``, :60-61); so does this."""
+    import os
+    import numpy as np
+    from ..utils import npy_io
+    feat_dir = os.path.join(indir, vid_name, 'cube_feat')
+    seq = sorted(f for f in os.listdir(feat_dir) if f.endswith('.npy'))
+    n_win = len(seq) - num_subseq                     # idx = 0 .. len(seq) - num_subseq - 1
+    if n_win <= 0:
+        return np.zeros((0, 0, 0), dtype=np.float32)
+    feats = np.stack([npy_io.cube_feat_to_cam_nhwc(np.load(os.path.join(feat_dir, f))) for f in seq])
+    w = int(round((feats.shape[1] // 6) ** 0.5))
+    dev = next(cell.parameters()).device
+    cam = torch.from_numpy(feats).to(dev)
+    maps = []
+    for lo in range(0, n_win, max_windows):
+        nb = min(max_windows, n_win - lo)
+        runner = ClipRunner(cell, c2e, nb, num_subseq, w)
+        maps.append(runner.run(cam[lo:lo + nb + num_subseq - 1], sliding=True).cpu().numpy())
+    maps = np.concatenate(maps)
+    if output_dir is not None:
+        for idx in range(n_win):
+            npy_io.save_saliency(output_dir, vid_name, idx + num_subseq - 1, maps[idx])
+    return maps

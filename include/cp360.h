@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 202
+#define CP360_VERSION 204
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -132,7 +132,11 @@ int cp360_resize_ksize(int in_size, int out_size);
 /* HOST: Pillow's coefficient tables for one axis.  bounds int32 [out_size][2] = (first input
  * index, tap count), kk int32 [out_size][ksize] 22-bit fixed point.  Returns ksize. */
 int cp360_resize_coeffs_host(int in_size, int out_size, int* bounds, int* kk);
-/* in u8 [F, h_in, w_in, 3] -> out u8 [F, h_out, w_out, 3] (device).  Tables are DEVICE copies of
+/* The same for Pillow's other filters: filter 0 = LANCZOS (support 3), 1 = BICUBIC (a = -0.5, support 2 -
+ * utils/utils.py:21, the overlay's heatmap.resize(..., resample=Image.CUBIC)). */
+int cp360_resize_ksize2(int in_size, int out_size, int filter);
+int cp360_resize_coeffs_host2(int in_size, int out_size, int filter, int* bounds, int* kk);
+/* in u8 [F, h_in, w_in, 3] -> out u8 [F, h_out, w_out, 3] (device); the filter is whatever the tables hold.  Tables are DEVICE copies of
  * cp360_resize_coeffs_host(w_in, w_out) / (h_in, h_out); tmp u8 [F, h_in, w_out, 3] is needed
  * when both axes change (horizontal pass first, as Pillow). */
 int cp360_resize_lanczos_u8(const void* in, void* out, void* tmp, int F, int h_in, int w_in,
@@ -312,6 +316,43 @@ int cp360_window_minmax(const float* x, float* minmax, float* scratch /* [B*256*
 int cp360_window_normalize(const float* x, const float* minmax, void* y, int y_dtype,
                            int ld_y, int y_coff, float* y2, int B, int T, int t,
                            int P, int C, size_t clip_stride, void* stream);
+
+/* ------------------------------------------------------------------ K9: overlay renderer
+ * utils/utils.py:9-25 as used by temporal_model/test_temporal.py:90-97.
+ * cp360_overlay_colorize: heat f32 [h, w] (optionally squared first, test_temporal.py:94) -> min-max
+ * normalised in float32 as numpy does -> 256-entry colormap lookup as matplotlib's Colormap.__call__(bytes=True)
+ * -> rgb u8 [h, w, 3].  lut768: device u8 [256, 3] (the shim builds 'jet' on the host).  The bicubic upsample
+ * is cp360_resize_lanczos_u8 with cp360_resize_coeffs_host2(filter = 1) tables.
+ * cp360_overlay_blend_u8: PIL.Image.blend: out = (u8)(img + alpha * (heat - img)), float arithmetic, 0 <= alpha <= 1. */
+int cp360_overlay_colorize(const float* heat, int h, int w, int square, const uint8_t* lut768, uint8_t* rgb,
+                           void* stream);
+int cp360_overlay_blend_u8(const uint8_t* img, const uint8_t* heat_rgb, uint8_t* out, long long n_bytes,
+                           float alpha, void* stream);
+
+/* ------------------------------------------------------------------ K8: saliency metrics
+ * utils/eval_saliency.py on the device: AUC_Judd (:90-146), AUC_Borji (:14-87), CorrCoeff (:149-176),
+ * similarity (:179-190).  Every reference metric first resizes both maps with
+ * cv2.resize(x, (240, 120), cv2.INTER_LANCZOS4) - the flag lands in the `dst` slot, so OpenCV's default
+ * INTER_LINEAR runs: cp360_resize_linear_f32.  The AUCs share cp360_metric_auc_prepare (normalised
+ * saliency + the values at fixated pixels, F > mean(F) + 2 std(F)) and a workspace of
+ * cp360_metric_work_bytes(n) bytes; all pointers are device memory.
+ */
+/* cv2.resize(src [h, w] f32, (dw, dh)) with INTER_LINEAR (half-pixel centres, edge clamp) -> dst [dh, dw]. */
+int cp360_resize_linear_f32(const float* src, int h, int w, float* dst, int dh, int dw, void* stream);
+size_t cp360_metric_work_bytes(int n);
+/* sal, fix: resized maps, n pixels each.  mode 0 (AUC_Judd): S = sal + jitter (f64 [n] or NULL, the
+ * reference's randn / 1e7), min-max normalised in f64.  mode 1 (AUC_Borji): S[S > mean + 2 std] = 1, then
+ * min-max normalised in f32.  work[0] (as double) = number of fixated pixels afterwards. */
+int cp360_metric_auc_prepare(const float* sal, const float* fix, const double* jitter, int n, int mode,
+                             void* work, void* stream);
+/* out2[0] = AUC-Judd, out2[1] = number of fixated pixels (doubles). */
+int cp360_metric_auc_judd(int n, void* work, double* out2, void* stream);
+/* rr int32 [n_fix, n_splits]: the reference's np.random.randint(0, n, (n_fix, n_splits)); aucs f64 [n_splits]
+ * (their mean is the score); step = the threshold spacing (0.01). */
+int cp360_metric_auc_borji(int n, int n_splits, const int* rr, double step, void* work, double* aucs,
+                           void* stream);
+/* out2[0] = CorrCoeff(a, b), out2[1] = similarity(a, b) of two resized maps (doubles). */
+int cp360_metric_cc_sim(const float* a, const float* b, int n, double* out2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,13 +79,55 @@ def _pass(img, bounds, kk, axis):
     return np.moveaxis(out, 0, axis)
 
 
-def resize_lanczos_u8(img, out_hw):
-    """img uint8 [H, W, C] -> uint8 [out_h, out_w, C] exactly as PIL (LANCZOS)."""
+def _bicubic(x):
+    """Pillow's bicubic_filter (Resample.c): Keys kernel, a = -0.5, support 2 - Image.CUBIC of
+    /root/reference/utils/utils.py:21."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+_FILTERS = {'lanczos': (3.0, _lanczos), 'bicubic': (2.0, _bicubic)}
+
+
+def resize_u8(img, out_hw, filter='lanczos'):
+    """img uint8 [H, W, C] -> uint8 [out_h, out_w, C] exactly as PIL's Image.resize with that filter."""
+    support, filt = _FILTERS[filter]
     h, w = img.shape[:2]
     oh, ow = out_hw
     cur = img
     if ow != w:
-        cur = _pass(cur, *precompute_coeffs(w, ow), axis=1)
+        cur = _pass(cur, *precompute_coeffs(w, ow, support, filt), axis=1)
     if oh != h:
-        cur = _pass(cur, *precompute_coeffs(h, oh), axis=0)
+        cur = _pass(cur, *precompute_coeffs(h, oh, support, filt), axis=0)
     return cur
+
+
+def resize_lanczos_u8(img, out_hw):
+    """img uint8 [H, W, C] -> uint8 [out_h, out_w, C] exactly as PIL (LANCZOS)."""
+    return resize_u8(img, out_hw, 'lanczos')
+
+
+def overlay(img_u8, heat, lut, alpha=0.5):
+    """/root/reference/utils/utils.py:9-25 restated: min-max normalise (in the map's dtype), 256-entry colormap
+    lookup as matplotlib's Colormap.__call__(bytes=True), PIL bicubic upsample, PIL.Image.blend."""
+    heat = np.asarray(heat)
+    heat = heat - np.min(heat)
+    heat = heat / np.max(heat)
+    xa = np.array(heat, copy=True)
+    xa *= 256
+    xa[xa == 256] = 255
+    bad = np.isnan(xa)
+    with np.errstate(invalid='ignore'):
+        idx = np.clip(xa, 0, 255).astype(int)
+    rgb = lut[idx]
+    rgb[bad] = 0
+    up = resize_u8(rgb.astype(np.uint8), img_u8.shape[:2], 'bicubic')
+    a = img_u8.astype(np.int32)
+    out = a.astype(np.float32) + np.float32(alpha) * (up.astype(np.int32) - a).astype(np.float32)
+    return out.astype(np.uint8)

@@ -6,7 +6,7 @@ reference is imported in memory with the shims listed in SURVEY.md section 8(c);
 nothing of its source is written to this repo - the fixtures are inputs (or their
 hash-RNG seeds) and the reference's outputs.
 
-    python tests/golden/make_golden.py [--only cubepad,e2c,c2e,resnet,clstm,resize,metrics]
+    python tests/golden/make_golden.py [--only cubepad,e2c,c2e,resnet,clstm,resize,metrics,overlay]
 
 Shims (all in memory):
   * ``np.int = int``  (alias removed in numpy >= 1.24; cube_pad.py:13,64)
@@ -302,14 +302,49 @@ def gen_metrics(R, out):
     print('metrics fixtures written', {k: float(v) for k, v in arrs.items()})
 
 
+# --------------------------------------------------------------------------- overlay (f4)
+OVERLAY_CASES = [((14, 28), (96, 192), 0.5), ((32, 64), (128, 256), 0.5), ((7, 9), (50, 61), 0.3)]
+
+
+def overlay_inputs(k):
+    (h, w), (H, W), alpha = OVERLAY_CASES[k]
+    heat = (hashrng.uniform(8500 + k, (h, w)) ** 2).astype(np.float32)          # test_temporal.py:94 squares the map
+    img = hashrng.uniform(8600 + k, (H, W, 3), 0.0, 256.0).astype(np.uint8)
+    return img, heat, alpha
+
+
+def gen_overlay(out):
+    """utils/utils.py:9-25 executed from the reference (imports only PIL + matplotlib, both in this image).
+    In-memory shim: ``Image.CUBIC = Image.BICUBIC`` (the alias was removed in Pillow 10; same filter)."""
+    import importlib
+    import warnings
+    import matplotlib
+    from PIL import Image
+    matplotlib.use('Agg')
+    if not hasattr(Image, 'CUBIC'):
+        Image.CUBIC = Image.BICUBIC
+    warnings.simplefilter('ignore')
+    sys.path.insert(0, REF)
+    uu = importlib.import_module('utils.utils')
+    arrs = {}
+    for k in range(len(OVERLAY_CASES)):
+        img, heat, alpha = overlay_inputs(k)
+        arrs['y%d' % k] = np.array(uu.overlay(img.copy(), heat.copy(), alpha=alpha))
+    np.savez_compressed(os.path.join(out, 'overlay.npz'), **arrs)
+    print('overlay fixtures written')
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--only', default='cubepad,e2c,c2e,resnet,clstm,resize,metrics')
+    ap.add_argument('--only', default='cubepad,e2c,c2e,resnet,clstm,resize,metrics,overlay')
     args = ap.parse_args()
     parts = args.only.split(',')
     if 'resize' in parts:                      # Pillow only: the reference itself is not needed
         gen_resize(HERE)
         parts.remove('resize')
+    if 'overlay' in parts:
+        gen_overlay(HERE)
+        parts.remove('overlay')
     if not parts:
         return
     R = import_reference()

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from cp_360_weakly_supervised_saliency_amd.utils import npy_io, synth
 
@@ -27,3 +28,32 @@ def test_saliency_file_name(tmp_path):
     npy_io.save_saliency(str(tmp_path), 'clip7', 12, sal)
     got = np.load(tmp_path / 'clip7' / '00012.npy')                    # test_temporal.py:86-88
     assert got.dtype == np.float32 and np.array_equal(got, sal.astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_reference_layout_files_through_gpu_temporal_stage(tmp_path, golden_dir):
+    """f2 end to end: cube_feat files written the way the reference's static stage writes them
+    (dataset_feat_extractor.py:187-189: np.save of float32 [6, 1000, 7, 7] as cube_feat/{:06}.npy) are read by
+    the build's file driver, go through the GPU ConvLSTM, and the saved {:05}.npy map (test_temporal.py:86-88)
+    reproduces the reference's own output for that window (tests/golden/clstm.npz: full_map_T5)."""
+    import torch
+    from cp_360_weakly_supervised_saliency_amd.model.clstm import ConvLSTMCell
+    from cp_360_weakly_supervised_saliency_amd.temporal_model.test_temporal import infer_video_dir
+    from cp_360_weakly_supervised_saliency_amd.utils.cube_to_equi import Cube2Equi
+    T = 5
+    frames = synth.cam_clip(6000 + T, T)                                # the golden window's inputs [T, 6, 1000, 7, 7]
+    extra = synth.cam_clip(6900, 2)                                     # two more frames: three windows in the video
+    vid = tmp_path / 'in' / 'vid0' / 'cube_feat'
+    os.makedirs(vid)
+    for t, f in enumerate(list(frames) + list(extra)):
+        np.save(vid / '{0:06}.npy'.format(t + 2), f.astype(np.float32))          # the extractor's counter starts at 2
+    cell = ConvLSTMCell(1000, 1000, precision='fp32')
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in synth.clstm_state(seed=2).items()})
+    cell = cell.cuda().eval()
+    maps = infer_video_dir(cell, Cube2Equi(7), str(tmp_path / 'in'), 'vid0', str(tmp_path / 'out'), num_subseq=T)
+    assert maps.shape == (2, 14, 28)                                    # 7 frames, windows idx 0 and 1 (the last is skipped)
+    saved = np.load(tmp_path / 'out' / 'vid0' / '00004.npy')            # window 0 ends at frame index 4
+    z = np.load(os.path.join(golden_dir, 'clstm.npz'))
+    assert saved.dtype == np.float32 and np.array_equal(saved, maps[0])
+    assert np.max(np.abs(saved - z['full_map_T5'])) <= 1e-3
+    assert os.path.exists(tmp_path / 'out' / 'vid0' / '00005.npy')
