@@ -2,6 +2,7 @@
 // NHWC for the fused pipeline) + the host-side table export.
 // Semantics: model/cube_pad.py:28-42,95-216 (see common.h: cubepad_src).
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------- NCHW
 // One workgroup per (group g, channel c): it writes the 6 padded planes of that
@@ -33,10 +34,180 @@ __global__ __launch_bounds__(256) void cubepad_nchw_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------- NCHW, 16-byte chunks + LDS-staged border strips
+// The element-per-lane kernel above moves 1-4 bytes per lane and runs cubepad_src() for every element:
+// 0.09-0.17 of the HBM peak (profiles/r02_hbm_kernels.md).  A padded plane [Hp, Wp] is one contiguous byte range,
+// and all but ~2 of the 16-byte chunks of a centre row are 16 consecutive bytes of the input plane: those go
+// straight through (one possibly misaligned 16-byte load - unaligned global access is on under ROCm - and
+// one ALIGNED 16-byte store).  Everything a pad element can read lies within P = max pad of a face border
+// (cube_pad.py:114-216 copies border strips of the neighbouring faces, corners replicate a strip's end): the
+// the four pad strips of a face (output orientation) are gathered into LDS once per (plane, face) and the
+// chunks that touch padding are assembled element by element from there; the <= 4 p^2 corner elements go through
+// cubepad_src() directly.  One WAVE per (group, channel, face) item, 32-bit index arithmetic, divisions by
+// Wp / n through a float reciprocal + correction.  ES = element bytes.
+template <int ES> struct ElemOf;
+template <> struct ElemOf<1> { typedef uint8_t T; };
+template <> struct ElemOf<2> { typedef uint16_t T; };
+template <> struct ElemOf<4> { typedef uint32_t T; };
+template <> struct ElemOf<8> { typedef uint64_t T; };
+typedef __attribute__((ext_vector_type(4))) unsigned int cp_u32x4;
+
+template <int ES>
+__global__ __launch_bounds__(256) void cubepad_nchw_strip_kernel(const unsigned char* __restrict__ x,
+                                                                 unsigned char* __restrict__ y, int C, CubePadGeom g,
+                                                                 int n_items, float rcp_wp, float rcp_n) {
+    typedef typename ElemOf<ES>::T T;
+    constexpr int E = 16 / ES;                               // elements per 16-byte chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char strip_raw[];
+    const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nstrip = (g.pt + g.pd + g.pl + g.pr) * n;      // one wave's strips: top [pt][n], bottom [pd][n], left [pl][n], right [pr][n]
+    T* st = reinterpret_cast<T*>(strip_raw) + (size_t)wave * nstrip;
+    const T* st_t = st;
+    const T* st_b = st_t + g.pt * n;
+    const T* st_l = st_b + g.pd * n;
+    const T* st_r = st_l + g.pl * n;
+    const size_t in_face = (size_t)C * n * n, out_face = (size_t)C * Hp * Wp;
+    const int plane_elems = Hp * Wp;
+    // exact unsigned division by a small constant through a float reciprocal + one correction (operands < 2^24)
+    auto div_by = [](int q, int d, float rcp) -> int {
+        int r = (int)((float)q * rcp);
+        r -= (r * d > q);
+        r += ((r + 1) * d <= q);
+        return r;
+    };
+    // a (plane, face) item per WAVE: small planes (14x14, 7x7 faces) would leave a 256-thread workgroup idle
+    for (int item = blockIdx.x * 4 + wave; item < n_items; item += gridDim.x * 4) {
+        const int plane = item / 6, f = item - plane * 6;
+        const int grp = plane / C, c = plane - grp * C;
+        const T* xin = reinterpret_cast<const T*>(x) + (size_t)grp * 6 * in_face + (size_t)c * n * n;
+        const T* xf = xin + (size_t)f * in_face;
+        auto src_elem = [&](int i, int j) -> T {            // any padded position through the CubePad map (global gather)
+            const int s = cubepad_src(f, i, j, g);
+            const int sf = div_by(s, n * n, rcp_n * rcp_n);
+            return xin[(size_t)sf * in_face + (s - sf * n * n)];
+        };
+        // ---- stage this face's four pad strips (output orientation, corners excluded) in LDS
+        for (int idx = lane; idx < nstrip; idx += 64) {
+            const int k = div_by(idx, n, rcp_n), a = idx - k * n;
+            int i, j;
+            if (k < g.pt)                      { i = k;                              j = g.pl + a; }
+            else if (k < g.pt + g.pd)          { i = g.pt + n + (k - g.pt);          j = g.pl + a; }
+            else if (k < g.pt + g.pd + g.pl)   { i = g.pt + a;                       j = k - g.pt - g.pd; }
+            else                               { i = g.pt + a;                       j = g.pl + n + (k - g.pt - g.pd - g.pl); }
+            st[idx] = src_elem(i, j);
+        }
+        __builtin_amdgcn_wave_barrier();
+        auto elem = [&](int i, int j) -> T {
+            const bool ri = i >= g.pt && i < g.pt + n, cj = j >= g.pl && j < g.pl + n;
+            if (ri && cj) return xf[(size_t)(i - g.pt) * n + (j - g.pl)];
+            if (cj) return i < g.pt ? st_t[i * n + (j - g.pl)] : st_b[(i - g.pt - n) * n + (j - g.pl)];
+            if (ri) return j < g.pl ? st_l[j * n + (i - g.pt)] : st_r[(j - g.pl - n) * n + (i - g.pt)];
+            return src_elem(i, j);                           // corner stitch (at most 4 p^2 elements per plane)
+        };
+        unsigned char* yb = y + ((size_t)grp * 6 * out_face + (size_t)f * out_face + (size_t)c * Hp * Wp) * ES;
+        // 16-byte-aligned chunks of the tensor's address range that overlap this plane.  Chunk ch holds plane
+        // elements [ch * E - head, ch * E - head + E); the chunks fully inside a centre row's centre columns
+        // ("runs": rows' chunk ranges [cs(r), ce(r))) are plain copies, everything else is assembled per element.
+        const size_t a0 = reinterpret_cast<size_t>(yb), a1 = a0 + (size_t)plane_elems * ES;
+        const size_t c0 = a0 & ~(size_t)15;
+        const int head = (int)(a0 - c0) / ES;                // elements of chunk 0 that belong to the previous plane
+        const int nchunks = (int)((a1 - c0 + 15) >> 4);
+        auto run_begin = [&](int r) -> int {                 // first chunk fully inside centre row r (r = 0 .. n-1)
+            return ((g.pt + r) * Wp + g.pl + head + E - 1) / E;   // (operands < 2^23: exact integer division is cheap enough per row)
+        };
+        auto run_end = [&](int r) -> int { return ((g.pt + r) * Wp + g.pl + n + head) / E; };
+        auto slow_chunk = [&](int ch) __attribute__((always_inline)) {
+            const int q0 = ch * E - head;
+            unsigned char* ca = reinterpret_cast<unsigned char*>(c0 + ((size_t)ch << 4));
+            if (q0 >= 0 && q0 + E <= plane_elems) {
+                const int i = div_by(q0, Wp, rcp_wp), j = q0 - i * Wp;
+                T tmp[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    int ie = i, je = j + e;
+                    if (je >= Wp) { je -= Wp; ++ie; }        // E <= Wp (launcher)
+                    tmp[e] = elem(ie, je);
+                }
+                cp_u32x4 v;
+                __builtin_memcpy(&v, tmp, 16);
+                *reinterpret_cast<cp_u32x4*>(ca) = v;
+            } else {                                         // head / tail of the plane: element stores
+                for (int e = 0; e < E; ++e) {
+                    const int q = q0 + e;
+                    if (q < 0 || q >= plane_elems) continue;
+                    const int ie = div_by(q, Wp, rcp_wp), je = q - ie * Wp;
+                    reinterpret_cast<T*>(yb)[q] = elem(ie, je);
+                }
+            }
+        };
+        // ---- pass 1: the runs.  cpr = chunks per row upper bound; lanes enumerate (row, chunk in run), four at a time
+        const int cpr = n * ES / 16 + 1;
+        const float rcp_cpr = 1.0f / (float)cpr;
+        const int nfast = n * cpr;
+        for (int base = lane; base < nfast; base += 64 * 4) {
+            cp_u32x4 v[4];
+            unsigned char* dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + 64 * u;
+                dst[u] = nullptr;
+                if (idx < nfast) {
+                    const int r = div_by(idx, cpr, rcp_cpr), k = idx - r * cpr;
+                    const int ch = run_begin(r) + k;
+                    if (ch < run_end(r)) {
+                        const int j = ch * E - head - (g.pt + r) * Wp;       // first column of the chunk (>= pl)
+                        __builtin_memcpy(&v[u], xf + (size_t)r * n + (j - g.pl), 16);
+                        dst[u] = reinterpret_cast<unsigned char*>(c0 + ((size_t)ch << 4));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u]) *reinterpret_cast<cp_u32x4*>(dst[u]) = v[u];
+        }
+        // ---- pass 2: what the runs leave: the pad rows above / below and the 1-2 chunks between consecutive runs
+        {
+            const int top_end = min(run_begin(0), nchunks);
+            for (int ch = lane; ch < top_end; ch += 64) slow_chunk(ch);
+            const int bot_begin = max(run_end(n - 1), top_end);
+            for (int ch = bot_begin + lane; ch < nchunks; ch += 64) slow_chunk(ch);
+            for (int r = 1 + lane; r < n; r += 64) {
+                const int lo = max(run_end(r - 1), top_end), hi = min(run_begin(r), bot_begin);
+                for (int ch = lo; ch < hi; ++ch) slow_chunk(ch);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                     // the next item's staging overwrites the strips
+    }
+}
+
 template <typename T>
 static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom& g, hipStream_t st) {
     const int Wp = g.n + g.pl + g.pr;
     const int planes = (n6 / 6) * C;
+    {   // strip kernel: pads of at most 4 (every pad of the network is 1 or 3), strips within the 64 KiB LDS default
+        const int P = max(max(g.pl, g.pr), max(g.pt, g.pd));
+        constexpr int ES = (int)sizeof(T);
+        const int Hp = g.n + g.pt + g.pd;
+        const size_t lds = (size_t)4 * (g.pt + g.pd + g.pl + g.pr) * g.n * ES;      // four waves' strips
+        static const int no_strip = []() {
+            const char* e = getenv("CP360_CUBEPAD_ELEMENTWISE");      // A/B switch (tools/hbm_kernels.py)
+            return e ? atoi(e) : 0;
+        }();
+        // (rows of at least 128 bytes: on the small faces of layer3/4 and the ConvLSTM almost every chunk touches
+        //  padding and the element-per-lane kernel below is faster - measured, profiles/r02_hbm_kernels.md)
+        if (!no_strip && P >= 1 && P <= g.n && g.n * ES >= 128 && lds <= 64 * 1024 && (long long)Hp * Wp < (1 << 22) &&
+            (reinterpret_cast<size_t>(y) % ES) == 0) {
+            const long long items = (long long)planes * 6;
+            long long blocks = (items + 3) / 4;
+            if (blocks > 256 * 32) blocks = 256 * 32;
+            hipLaunchKernelGGL((cubepad_nchw_strip_kernel<ES>), dim3((unsigned)blocks), dim3(256), lds, st,
+                               (const unsigned char*)x, (unsigned char*)y, C, g, (int)items, 1.0f / (float)Wp,
+                               1.0f / (float)g.n);
+            CP360_CHECK_HIP();
+            return CP360_OK;
+        }
+    }
     if (Wp <= 16)
         hipLaunchKernelGGL((cubepad_nchw_kernel<T, 4>), dim3(planes), dim3(256), 0, st, (const T*)x, (T*)y, C, g);
     else if (Wp <= 32)

@@ -9,6 +9,11 @@
 // jitter) and float64 for the sums (the reference's float32 pairwise sums differ from them by ~1e-7 relative).
 #include "common.h"
 
+// numpy / Pillow evaluate a * b + c as two rounded operations: no FMA contraction in this file (HIP's default
+// -ffp-contract=fast would fuse them and change the last bit).  Plain operators only: HIP's __fadd_rn / __fmul_rn are header
+// functions compiled with contraction ON, and their instructions keep that flag when inlined here.
+#pragma clang fp contract(off)
+
 namespace {
 
 // cv2.resize INTER_LINEAR for one axis: source index / fraction of destination index d
@@ -35,9 +40,9 @@ __global__ __launch_bounds__(256) void resize_linear_kernel(const float* __restr
     lin_axis(x, w, dw, x0, x1, fx);
     // same operation order as the oracle (and float32 throughout): rows first, then the vertical blend
     const float a = src[y0 * w + x0], b = src[y0 * w + x1], c = src[y1 * w + x0], d = src[y1 * w + x1];
-    const float top = __fadd_rn(__fmul_rn(a, __fsub_rn(1.f, fx)), __fmul_rn(b, fx));
-    const float bot = __fadd_rn(__fmul_rn(c, __fsub_rn(1.f, fx)), __fmul_rn(d, fx));
-    dst[idx] = __fadd_rn(__fmul_rn(top, __fsub_rn(1.f, fy)), __fmul_rn(bot, fy));
+    const float top = a * (1.f - fx) + b * fx;
+    const float bot = c * (1.f - fx) + d * fx;
+    dst[idx] = top * (1.f - fy) + bot * fy;
 }
 
 // ---- block-wide reductions (1024 threads)
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(1024) void auc_prepare_kernel(const float* __restri
         const float fmn = (float)block_reduce(mn, OpMin(), sm), fmx = (float)block_reduce(mx, OpMax(), sm);
         for (int i = tid; i < n; i += 1024) {
             const float v = sal[i] > sthr ? 1.0f : sal[i];
-            S[i] = (double)__fdiv_rn(__fsub_rn(v, fmn), __fsub_rn(fmx, fmn));
+            S[i] = (double)((v - fmn) / (fmx - fmn));
         }
     } else {
         double mn = 1e300, mx = -1e300;

@@ -7,6 +7,11 @@
 // (UINT8)(in1 + alpha * (in2 - in1)) in float for the blend.
 #include "common.h"
 
+// numpy / Pillow evaluate a * b + c as two rounded operations: no FMA contraction in this file (HIP's default
+// -ffp-contract=fast would fuse them and change the last bit).  Plain operators only: HIP's __fadd_rn / __fmul_rn are header
+// functions compiled with contraction ON, and their instructions keep that flag when inlined here.
+#pragma clang fp contract(off)
+
 namespace {
 __global__ __launch_bounds__(1024) void overlay_colorize_kernel(const float* __restrict__ heat, int n, int square,
                                                                 const uint8_t* __restrict__ lut /* [256, 3] */,
@@ -17,7 +22,7 @@ __global__ __launch_bounds__(1024) void overlay_colorize_kernel(const float* __r
     bool nan = false;
     for (int i = tid; i < n; i += 1024) {
         float v = heat[i];
-        if (square) v = __fmul_rn(v, v);                      // test_temporal.py:94: equi_output ** 2
+        if (square) v = ((v) * (v));                      // test_temporal.py:94: equi_output ** 2
         nan |= v != v;
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -35,12 +40,12 @@ __global__ __launch_bounds__(1024) void overlay_colorize_kernel(const float* __r
         __syncthreads();
     }
     const float gmn = smn[0];
-    const float gmx = __fsub_rn(smx[0], gmn);                 // max of (heat - min) = max - min (rounding is monotone)
+    const float gmx = ((smx[0]) - (gmn));                 // max of (heat - min) = max - min (rounding is monotone)
     for (int i = tid; i < n; i += 1024) {
         float v = heat[i];
-        if (square) v = __fmul_rn(v, v);
-        v = __fdiv_rn(__fsub_rn(v, gmn), gmx);
-        float xa = __fmul_rn(v, 256.f);
+        if (square) v = ((v) * (v));
+        v = (v - gmn) / gmx;
+        float xa = v * 256.f;
         if (xa == 256.f) xa = 255.f;
         uint8_t r = 0, g = 0, b = 0;                          // "bad" (NaN): (0, 0, 0, 0)
         if (xa == xa) {
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(256) void overlay_blend_kernel(const uint8_t* __res
                                                             uint8_t* __restrict__ out, float alpha, long long n) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int x = a[i], y = b[i];
-        out[i] = (uint8_t)__fadd_rn((float)x, __fmul_rn(alpha, (float)(y - x)));
+        out[i] = (uint8_t)((float)x + alpha * (float)(y - x));
     }
 }
 }  // namespace

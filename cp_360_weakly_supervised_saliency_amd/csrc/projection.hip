@@ -1,6 +1,7 @@
 // K1 equi -> cube (+ /255, ImageNet normalise, layout, dtype) and K6 cube -> equi
 // (+ channel max).  Both are gathers bounded by HBM bandwidth.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ K1
 // utils/equi_to_cube.py:112-129 = cv2.remap(img[:, :, c], inX, inY, INTER_LINEAR) per
@@ -24,12 +25,11 @@ template <> __device__ __forceinline__ f16_raw out_cvt<f16_raw>(float v) { retur
 // A thread owns one output pixel g of FU consecutive frames: the grid point, the fixed-point split and
 // the bilinear weights are computed once, and the 2 x FU row loads of the frames are in flight together
 // (the one-pixel-one-frame form spent its time in two dependent round trips per output: grid, then taps).
-template <typename TI, typename TO, int LAYOUT, bool FIXED>
+template <typename TI, typename TO, int LAYOUT, bool FIXED, int FU>
 __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ equi, const float2* __restrict__ grid,
                                                         TO* __restrict__ out, int F, int H, int W, int cd,
                                                         float m0, float m1, float m2, float s0, float s1, float s2,
                                                         float scale) {
-    constexpr int FU = 4;
     const long long per_frame = 6LL * cd * cd;
     const int nfc = (F + FU - 1) / FU;
     const long long total = per_frame * nfc;
@@ -131,15 +131,20 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
 template <typename TI, typename TO>
 static int launch_e2c(const void* equi, const float* grid, void* out, int F, int H, int W, int cd, const float* mean,
                       const float* istd, float scale, int layout, int fixed, hipStream_t st) {
-    const long long total = (long long)((F + 3) / 4) * 6 * cd * cd;      // one thread per pixel and group of 4 frames
+    static const int fu_env = []() { const char* e = getenv("CP360_E2C_FU"); return e ? atoi(e) : 0; }();
+    static const int cap_env = []() { const char* e = getenv("CP360_E2C_CAP"); return e ? atoi(e) : 64; }();
+    const int fu = (fu_env == 8 || (fu_env == 0 && false)) ? 8 : (fu_env == 2 ? 2 : 4);
+    const long long total = (long long)((F + fu - 1) / fu) * 6 * cd * cd;      // one thread per pixel and group of FU frames
     long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-#define E2C_LAUNCH(L, FX)                                                                                       \
-    hipLaunchKernelGGL((equi2cube_kernel<TI, TO, L, FX>), dim3((unsigned)blocks), dim3(256), 0, st,             \
+    if (blocks > 256LL * cap_env) blocks = 256LL * cap_env;
+#define E2C_LAUNCH(L, FX, FUV)                                                                                  \
+    hipLaunchKernelGGL((equi2cube_kernel<TI, TO, L, FX, FUV>), dim3((unsigned)blocks), dim3(256), 0, st,        \
                        (const TI*)equi, (const float2*)grid, (TO*)out, F, H, W, cd, mean[0], mean[1], mean[2],  \
                        istd[0], istd[1], istd[2], scale)
-    if (layout == 0) { if (fixed) E2C_LAUNCH(0, true); else E2C_LAUNCH(0, false); }
-    else             { if (fixed) E2C_LAUNCH(1, true); else E2C_LAUNCH(1, false); }
+#define E2C_FU(L, FX) { if (fu == 8) E2C_LAUNCH(L, FX, 8); else if (fu == 2) E2C_LAUNCH(L, FX, 2); else E2C_LAUNCH(L, FX, 4); }
+    if (layout == 0) { if (fixed) E2C_FU(0, true) else E2C_FU(0, false) }
+    else             { if (fixed) E2C_FU(1, true) else E2C_FU(1, false) }
+#undef E2C_FU
 #undef E2C_LAUNCH
     CP360_CHECK_HIP();
     return CP360_OK;
