@@ -1,0 +1,321 @@
+// K3e: the tail of a layer2 identity Bottleneck in ONE kernel (16-bit types, 28x28 cube faces):
+//
+//   mid [.,28,28,128] --CubePad(1)+conv3x3 128->128 +bn2+relu--> t --conv1x1 128->512 +bn3 + residual + relu--> out
+//
+// (conv2 / conv3 / residual add of model/resnet_cubic.py:85-106 for layer2's blocks 1-3).  Separately these are a
+// generic implicit GEMM that re-gathers its im2col rows once per tap (conv2, 0.15 ms per block for 64 frames) and
+// an HBM-bound 1x1 (conv3, 0.15 ms) with t making a round trip through HBM in between.  Here, as in l1block.hip:
+//   * a workgroup (8 waves) owns TWO bands of 4 output rows (112 pixels = 7 MFMA pixel blocks each, no padding
+//     columns: a band's pixels are consecutive in memory); waves 0-3 work on band A, waves 4-7 on band B;
+//   * stage 1 (conv2): each band's 6 x 30 cube-padded pixels (256 B each, 45 KB) are gathered ONCE by LDS-DMA through
+//     cubepad_src(); the nine taps read them there (pixel p's 16-byte chunk c sits at chunk c ^ (p & 15): 16
+//     consecutive pixels cover the 16 slots of the 256-byte bank row).  Wave w computes the 32-channel row pair
+//     (w & 3) for all 7 pixel blocks of its band; its A fragments (4 KiB per half tap) come from L2 straight into
+//     registers, three half taps ahead - no LDS ring and no barrier inside the stage;
+//   * stage 2: t = relu(conv2 + b2), rounded once, goes to LDS ([112 px][128 ch], 272-byte pixel stride) - the
+//     K reduction of conv3 needs all four waves' channels - where the band's patch was;
+//   * stage 3 (conv3): wave w computes the 32-channel pairs w&3, +4, +8, +12 of the 512 outputs (K = 128: 56 MFMAs
+//     per pass), A fragments from L2 (fragment order, prefetched one pass ahead), adds the residual piece (16-byte
+//     loads prefetched one pass ahead), ReLU, one rounding, 16-byte stores.
+// HBM traffic per block (64 frames): mid 77 MB + residual 308 MB + out 308 MB; t (77 MB x 2) never leaves the CU.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+namespace {
+constexpr int N = 28, NP = N + 2, C = 128, CO = 512, BAND = 4;
+constexpr int PX = BAND * N;                                 // 112 output pixels per band = 7 blocks of 16
+constexpr int PB = PX / 16;                                  // 7
+constexpr int PATCH_PX = (BAND + 2) * NP;                    // 180
+constexpr int PATCH_INST = PATCH_PX / 4;                     // 45 DMA instructions of 4 pixels x 256 B
+constexpr int PATCH_LDS = PATCH_INST * 1024;                 // 46,080
+constexpr int W_STEP = C * 128;                              // 16 KiB of conv2 weights per half tap (16 fragments)
+template <int NB> struct L2Geom {                            // NB = bands per workgroup (4 waves each)
+    static constexpr int OFF_BIAS = NB * PATCH_LDS;
+    static constexpr int LDS_BYTES = OFF_BIAS + (C + CO) * 4; // 48,640 (NB = 1: two workgroups per CU) / 94,720
+};
+constexpr int T_STRIDE = C * 2 + 16;                         // 272-byte pixel stride of the t tile
+static_assert(PX * T_STRIDE <= PATCH_LDS, "the t tile reuses its band's patch");
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ int w_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma<bf16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma<f16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], bf16_raw) {
+    u32x4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+__device__ __forceinline__ u32x4 pack8(const float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3],
+                      (f16_raw)v[4], (f16_raw)v[5], (f16_raw)v[6], (f16_raw)v[7]};
+    return __builtin_bit_cast(u32x4, h);
+}
+__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], bf16_raw) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
+    const f16x8v h = __builtin_bit_cast(f16x8v, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+}
+__host__ __device__ __forceinline__ int row_chan(int R) { return (R & ~31) + ((R >> 2) & 3) * 8 + ((R >> 4) & 1) * 4 + (R & 3); }
+}  // namespace
+
+// conv2 weights [128, 128, 3, 3] (times scale) -> MFMA A fragments [step s = tap * 2 + half][row block 8][kk 2]
+// [lane][8]: lane l holds row (l & 15) of the block (rows in acc_chan order), channels half*64 + kk*32 + (l>>4)*8 ..+7
+template <typename T>
+__global__ __launch_bounds__(256) void l2_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                      T* __restrict__ packed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 9 * C * C) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, kk = (idx >> 9) & 1, rb = (idx >> 10) & 7, st = idx >> 13;
+    const int tap = st >> 1, half = st & 1;
+    const int n = row_chan(rb * 16 + (lane & 15));
+    const int c = half * 64 + kk * 32 + (lane >> 4) * 8 + e;
+    const float v = w[((size_t)n * C + c) * 9 + tap] * (scale ? scale[n] : 1.f);
+    if constexpr (__is_same(T, f16_raw)) packed[idx] = (f16_raw)v;
+    else packed[idx] = f32_to_bf16(v);
+}
+
+template <typename T, int NB>
+__global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
+                                                         const float* __restrict__ bias2, const T* __restrict__ w3f,
+                                                         const float* __restrict__ bias3, const T* __restrict__ res,
+                                                         T* __restrict__ out) {
+    constexpr int OFF_BIAS = L2Geom<NB>::OFF_BIAS;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[L2Geom<NB>::LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half_wg = wave >> 2, w4 = wave & 3;              // band A / B of this workgroup, wave inside the band
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int gband = blockIdx.x * NB + half_wg;                // global band = img * 7 + band
+    const int img = gband / (N / BAND), band = gband - img * (N / BAND);
+    const int grp = img / 6, f = img - grp * 6;
+    const CubePadGeom geom{N, 1, 1, 1, 1};
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    const size_t pix0 = (size_t)gband * PX;                    // the band's first pixel (pixels of a band are consecutive)
+    unsigned char* patch = lds + half_wg * PATCH_LDS;
+
+    // ---- stage 1: gather the band's padded pixels: instruction i = patch pixels 4i .. 4i+3, 256 B each
+    {
+        const T* xg = x + (size_t)grp * 6 * N * N * C;
+#pragma unroll 1
+        for (int inst = w4; inst < PATCH_INST; inst += 4) {
+            const int q = inst * 4 + (lane >> 4);
+            const int pr = q / NP, pc = q - pr * NP;
+            const int sp = cubepad_src(f, BAND * band + pr, pc, geom);
+            const T* src = xg + (size_t)sp * C + (((lane & 15) ^ (q & 15)) << 3);
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_base + half_wg * PATCH_LDS + inst * 1024));
+        }
+    }
+    // conv2's A fragments come straight from L2 into registers, three steps ahead (a step = half a tap = 4
+    // fragments of this wave's row pair): ~96 KiB in flight per CU and no barrier in the whole stage - a ring
+    // in LDS (3 x 16 KiB, 2 steps ahead) left the stage waiting on L2 latency at every step (0.25 -> 0.17 ms)
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk2);
+    auto load_a = [&](int s, u32x4 (&a)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                a[i][kk] = *reinterpret_cast<const u32x4*>(wb + (size_t)s * W_STEP + (((w4 * 2 + i) * 2 + kk) * 64 + lane) * 16);
+    };
+    constexpr int DEPTH = 3;
+    u32x4 aq[DEPTH + 1][2][2];
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) load_a(s, aq[s]);
+
+    int pbase[PB];                                             // patch pixel (tap 0, 0) of this lane's pixel in block j
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int pl = j * 16 + lrow, r = pl / N;
+        pbase[j] = r * NP + (pl - r * N);
+    }
+    f32x4 acc[2][PB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the patch DMAs (and the first fragments)
+    __syncthreads();
+
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+        if (s + DEPTH < 18) load_a(s + DEPTH, aq[(s + DEPTH) % (DEPTH + 1)]);
+        const int tap = s >> 1, half = s & 1;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int poff = ky * NP + kx;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 b[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int p = pbase[j] + poff;
+                b[j] = *reinterpret_cast<const u32x4*>(patch + p * 256 + ((((half * 2 + kk) * 4 + lchunk) ^ (p & 15)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < PB; ++j) mma<T>(acc[i][j], aq[s % (DEPTH + 1)][i][kk], b[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                                           // every wave is done with the patches
+    // ---- stage 2: t = relu(conv2 + b2) -> the band's t tile (in place of its patch); biases -> LDS
+    float* bias_s = reinterpret_cast<float*>(lds + OFF_BIAS);
+    for (int i = tid; i < C + CO; i += 256 * NB) bias_s[i] = i < C ? (bias2 ? bias2[i] : 0.f) : bias3[i - C];
+    {
+        const int n = w4 * 32 + lchunk * 8;
+        float bb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[e] = bias2 ? bias2[n + e] : 0.f;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(acc[0][j][e] + bb[e], 0.f);
+                v[4 + e] = fmaxf(acc[1][j][e] + bb[4 + e], 0.f);
+            }
+            *reinterpret_cast<u32x4*>(patch + (j * 16 + lrow) * T_STRIDE + n * 2) = pack8(v, T());
+        }
+    }
+    // ---- stage 3: conv3 (+ residual, ReLU): 4 passes of 32 output channels per wave
+    auto load_a3 = [&](int p, u32x4 (&a)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                a[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(w3f) +
+                                                            ((size_t)((p * 2 + rb) * 4 + kb) * 64 + lane) * 16);
+    };
+    auto load_res = [&](int p, u32x4 (&r)[PB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            r[j] = *reinterpret_cast<const u32x4*>(res + (pix0 + j * 16 + lrow) * CO + p * 32 + lchunk * 8);
+    };
+    u32x4 a3[2][4], r[PB];
+    load_a3(w4, a3);
+    load_res(w4, r);
+    __syncthreads();                                           // the t tiles and the biases are complete
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int p = w4 + 4 * q;
+        u32x4 a3n[2][4], rn[PB];
+        if (q < 3) load_a3(p + 4, a3n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int j0 = 0; j0 < PB; j0 += 4) {               // pixel blocks in two groups (4 + 3): fewer live fragments
+                u32x4 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < PB)
+                        b[u] = *reinterpret_cast<const u32x4*>(patch + ((j0 + u) * 16 + lrow) * T_STRIDE + (kb * 4 + lchunk) * 16);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < PB) mma<T>(acc[rb][j0 + u], a3[rb][kb], b[u]);
+                __builtin_amdgcn_sched_barrier(0);             // keep the next group's fragment reads from being hoisted (spills)
+            }
+        }
+        if (q < 3) load_res(p + 4, rn);                        // lands under the next pass's MFMAs
+        const int n = p * 32 + lchunk * 8;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + C + n), b1 = *reinterpret_cast<const f32x4*>(bias_s + C + n + 4);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            float v[8], rv[8];
+            unpack8(r[j], rv, T());
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(acc[0][j][e] + b0[e] + rv[e], 0.f);
+                v[4 + e] = fmaxf(acc[1][j][e] + b1[e] + rv[4 + e], 0.f);
+            }
+            *reinterpret_cast<u32x4*>(out + (pix0 + j * 16 + lrow) * CO + n) = pack8(v, T());
+        }
+        if (q < 3) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) a3[rb][kb] = a3n[rb][kb];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) r[j] = rn[j];
+        }
+    }
+}
+
+extern "C" size_t cp360_l2block_packed_bytes(int dtype) {
+    return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)18 * W_STEP : 0;
+}
+
+extern "C" int cp360_l2block_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
+    if (!w_oihw || !packed) return CP360_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (9 * C * C + 255) / 256;
+    if (dtype == CP360_BF16)
+        hipLaunchKernelGGL((l2_pack_kernel<bf16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (bf16_raw*)packed);
+    else if (dtype == CP360_F16)
+        hipLaunchKernelGGL((l2_pack_kernel<f16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (f16_raw*)packed);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_l2block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                                     const void* w3_frags, const float* bias3, const void* residual, void* out,
+                                     int n_img, int face, void* stream) {
+    if (!mid || !w2_packed || !w3_frags || !bias3 || !residual || !out) return CP360_ERR_NULL;
+    if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
+    if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+    if (face != N) return CP360_ERR_UNSUPPORTED;
+    if ((long long)n_img * N * N * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    static const int nb_env = []() { const char* e = getenv("CP360_L2_BANDS"); return e ? atoi(e) : 1; }();   // A/B switch
+    const int nb = nb_env == 2 ? 2 : 1;
+    const dim3 grid((unsigned)(n_img * (N / BAND) / nb));      // n_img % 6 == 0: an even number of bands
+#define CP360_L2B(TT, NBV)                                                                                       \
+    hipLaunchKernelGGL((l2block_kernel<TT, NBV>), grid, dim3(256 * NBV), 0, st, (const TT*)mid, (const TT*)w2_packed, \
+                       bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out)
+    if (dtype == CP360_BF16) { if (nb == 2) CP360_L2B(bf16_raw, 2); else CP360_L2B(bf16_raw, 1); }
+    else if (dtype == CP360_F16) { if (nb == 2) CP360_L2B(f16_raw, 2); else CP360_L2B(f16_raw, 1); }
+#undef CP360_L2B
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

@@ -26,6 +26,7 @@ __all__ = ['ResNet', 'Bottleneck', 'resnet50']
 # A/B switch (tools, tests): False runs the downsample branch as its own convolution + residual add
 FUSE_DOWNSAMPLE = True
 FUSE_LAYER1 = True
+FUSE_LAYER2 = True
 
 
 
@@ -227,11 +228,33 @@ class ResNet(nn.Module):
             out, mid = fused[k](mid, residual=out)
         return out
 
+    def layer2_nhwc(self, x):
+        """layer2 on the fused path.  16-bit types at 28x28 output faces: the identity blocks run conv1 as a
+        convolution and conv2 -> conv3 + residual as ONE launch (csrc/l2block.hip); the first (stride-2,
+        downsample) block stays on the per-convolution path."""
+        dt = _DTYPES[self.precision]
+        blks = list(self.layer2)
+        x = blks[0].forward_nhwc(x)
+        if not (FUSE_LAYER2 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == 28 and x.shape[2] == 28
+                and all(b.downsample is None and b.stride == 1 for b in blks[1:])):
+            for blk in blks[1:]:
+                x = blk.forward_nhwc(x)
+            return x
+        stamp = _stamp(self.layer2, (self.precision,))
+        if getattr(self, '_l2', None) is None or stamp != self._l2_stamp:
+            c = lambda conv, bn: (conv.weight,) + _fold_bn(bn)
+            self._l2 = [ops.L2Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), dt, self.conv1.weight.device) for b in blks[1:]]
+            self._l2_stamp = stamp
+        for blk, tail in zip(blks[1:], self._l2):
+            x = tail(blk._plans()['c1'](x), x)
+        return x
+
     def features_nhwc(self, x_nhwc4, padded=False):
         """Fused path to layer4: [6N, H, W, 4] -> [6N, H/32, W/32, 2048]."""
         x = self.stem_nhwc(x_nhwc4, padded)
         x = self.layer1_nhwc(x)
-        for layer in (self.layer2, self.layer3, self.layer4):
+        x = self.layer2_nhwc(x)
+        for layer in (self.layer3, self.layer4):
             for blk in layer:
                 x = blk.forward_nhwc(x)
         return x

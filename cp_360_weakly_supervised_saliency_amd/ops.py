@@ -487,6 +487,40 @@ class L1Block:
         return out, nxt
 
 
+class L2Block:
+    """K3e (csrc/l2block.hip): the tail of a layer2 identity Bottleneck as ONE launch - conv2 + bn2 + relu ->
+    conv3 + bn3 + residual + relu.  16-bit types, 28x28 faces.  (weight, bn scale, bn bias) triples."""
+
+    def __init__(self, conv2, conv3, dtype=torch.float16, device='cuda'):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("L2Block runs in fp16 / bf16")
+        self.dtype, self.device = dtype, torch.device(device)
+        L, code = lib(), dtype_code(dtype)
+        f32 = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        w2, s2, b2 = conv2
+        w3, s3, b3 = conv3
+        if tuple(w2.shape) != (128, 128, 3, 3) or tuple(w3.shape[:2]) != (512, 128):
+            raise ValueError("L2Block is layer2's geometry: conv2 128->128 3x3, conv3 128->512 1x1")
+        self.w2 = torch.empty(L.cp360_l2block_packed_bytes(code), dtype=torch.uint8, device=self.device)
+        check(L.cp360_l2block_pack_weights(code, ptr(f32(w2)), ptr(f32(s2)), ptr(self.w2), stream()))
+        self.b2 = f32(b2)
+        self.w3 = frag_pack_1x1(w3, s3, dtype, 0, self.device)
+        self.b3 = f32(b3)
+
+    def __call__(self, mid, residual):
+        """mid [n_img, 28, 28, 128], residual [n_img, 28, 28, 512] -> out [n_img, 28, 28, 512]."""
+        require_gpu(mid, residual)
+        n_img = mid.shape[0]
+        _check_buf('mid', mid, self.dtype, (n_img, 28, 28, 128))
+        _check_buf('residual', residual, self.dtype, (n_img, 28, 28, 512))
+        if mid.shape[3] != 128 or residual.shape[3] != 512:
+            raise ValueError("dense NHWC tensors only")
+        out = torch.empty((n_img, 28, 28, 512), dtype=self.dtype, device=mid.device)
+        check(lib().cp360_l2block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
+                                          ptr(self.b3), ptr(residual), ptr(out), n_img, 28, stream()))
+        return out
+
+
 def cubepad_maxpool3s2(x):
     """CubePad(1) + MaxPool2d(3, 2, 0) on NHWC (resnet_cubic.py:169-170)."""
     require_gpu(x)

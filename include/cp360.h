@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 204
+#define CP360_VERSION 205
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -287,6 +287,19 @@ int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, con
                           const void* w3_frags, const float* bias3, const void* residual, const void* x_ds,
                           const void* wd_frags, void* out, const void* w1_frags, const float* bias1,
                           void* out_next, int n_img, int face, void* stream);
+
+/* ------------------------------------------------------------------ K3e: fused Bottleneck tail (layer2)
+ * conv2 (CubePad(1) + 3x3, 128 -> 128) + bn2 + relu -> conv3 (1x1, 128 -> 512) + bn3 + identity residual + relu
+ * of layer2's identity Bottlenecks (model/resnet_cubic.py:85-106) at cube size 224 (28x28 faces), CP360_BF16 /
+ * CP360_F16, in one kernel (csrc/l2block.hip).
+ *   mid [n_img, 28, 28, 128], w2_packed = cp360_l2block_pack_weights(w2 [128,128,3,3]), bias2 f32 [128],
+ *   w3_frags = cp360_frag_pack_1x1(w3 [512, 128], order 0), bias3 f32 [512],
+ *   residual / out [n_img, 28, 28, 512].  Other face sizes: CP360_ERR_UNSUPPORTED. */
+size_t cp360_l2block_packed_bytes(int dtype);
+int cp360_l2block_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream);
+int cp360_l2block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                          const void* w3_frags, const float* bias3, const void* residual, void* out,
+                          int n_img, int face, void* stream);
 
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),
