@@ -56,8 +56,13 @@ __global__ __launch_bounds__(256) void cubepad_maxpool16_kernel(const T* __restr
     const CubePadGeom g{n, 1, 1, 1, 1};
     const int cv = C / 8;
     const long long total = (long long)n6 * ho * ho * cv;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    // XCD-aware mapping (gridDim.x % 8 == 0): each XCD's L2 serves one contiguous eighth of the outputs - with the
+    // round-robin block order the input rows shared by neighbouring output rows crossed the fabric once per XCD
+    // (1.12 GB measured against 0.77 GB algorithmic, profiles/r02a_bf16.md)
+    const long long chunk = (total + 7) / 8;
+    const long long lo = (blockIdx.x & 7) * chunk, hi = min(total, lo + chunk);
+    const long long stride = (long long)(gridDim.x >> 3) * blockDim.x;
+    for (long long idx = lo + (long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; idx < hi; idx += stride) {
         const int c = (int)(idx % cv) * 8;
         long long t = idx / cv;
         const int ox = (int)(t % ho);
@@ -97,6 +102,7 @@ extern "C" int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, i
     const long long total = (long long)n6 * ho * ho * (C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    blocks = (blocks + 7) / 8 * 8;                   // the 16-byte kernel's XCD mapping
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CP360_F32)
         hipLaunchKernelGGL((cubepad_maxpool_kernel<float, 4>), dim3((unsigned)blocks), dim3(256), 0, st,

@@ -34,8 +34,16 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
     const int nfc = (F + FU - 1) / FU;
     const long long total = per_frame * nfc;
     const size_t frame_elems = (size_t)H * W * 3;
-    for (long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x; wi < total;
-         wi += (long long)gridDim.x * blockDim.x) {
+    // XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs (private L2s), so consecutive
+    // blocks - neighbouring output rows that sample the SAME input lines - would sit on 8 different L2s and every
+    // input line would cross the fabric up to 8 times (rocprofv3: 1.87 GB per launch against 0.41 GB algorithmic,
+    // profiles/r02a_bf16.md).  Each XCD takes one contiguous eighth of the (frame group, pixel) index space instead
+    // (= whole frame groups at the benchmark shape).  gridDim.x is a multiple of 8.
+    const long long chunk = (total + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const long long lo = xcd * chunk, hi = min(total, lo + chunk);
+    const long long stride = (long long)(gridDim.x >> 3) * blockDim.x;
+    for (long long wi = lo + (long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; wi < hi; wi += stride) {
         const int fc = (int)(wi / per_frame);
         const int g = (int)(wi - (long long)fc * per_frame);          // face*cd*cd + i*cd + j
         const int fr0 = fc * FU;
@@ -137,6 +145,7 @@ static int launch_e2c(const void* equi, const float* grid, void* out, int F, int
     const long long total = (long long)((F + fu - 1) / fu) * 6 * cd * cd;      // one thread per pixel and group of FU frames
     long long blocks = (total + 255) / 256;
     if (blocks > 256LL * cap_env) blocks = 256LL * cap_env;
+    blocks = (blocks + 7) / 8 * 8;                                  // XCD mapping in the kernel
 #define E2C_LAUNCH(L, FX, FUV)                                                                                  \
     hipLaunchKernelGGL((equi2cube_kernel<TI, TO, L, FX, FUV>), dim3((unsigned)blocks), dim3(256), 0, st,        \
                        (const TI*)equi, (const float2*)grid, (TO*)out, F, H, W, cd, mean[0], mean[1], mean[2],  \

@@ -101,6 +101,33 @@ def main():
                      'convs), WRITE_SIZE %.0f KiB per launch -> HBM traffic (2*FETCH + WRITE)*1024 = %.1f MB per '
                      'K=36000 launch (algorithmic: 297 MB packed weights + 19 MB activations + 75 MB slabs (4 splits))'
                      % (key, fe, sum(fv) / len(fv), wr, traffic / 1e6))
+    # per-kernel HBM bytes and GB/s: FETCH_SIZE / WRITE_SIZE averaged per launch and kernel name (counter passes),
+    # duration from the kernel-trace pass
+    if tr and find(os.path.join(src, 'fetch'), '*counter_collection.csv') and find(os.path.join(src, 'write'), '*counter_collection.csv'):
+        def short(n):
+            return n.split('(')[0].replace('void ', '')[:56]
+        dur = {}
+        for r in csv.DictReader(open(tr)):
+            dur.setdefault(short(r['Kernel_Name']), []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        cnt = {'fetch': {}, 'write': {}}
+        for name in ('fetch', 'write'):
+            for r in csv.DictReader(open(find(os.path.join(src, name), '*counter_collection.csv'))):
+                cnt[name].setdefault(short(r['Kernel_Name']), []).append(float(r['Counter_Value']))
+        tab = []
+        for k, d in dur.items():
+            if k in cnt['fetch'] and k in cnt['write'] and not k.startswith('at::') and 'pack' not in k:
+                fe = sum(cnt['fetch'][k]) / len(cnt['fetch'][k])
+                wr = sum(cnt['write'][k]) / len(cnt['write'][k])
+                us = sum(d) / len(d)
+                by = (2 * fe + wr) * 1024
+                tab.append((sum(d), k, len(d), us, by, by / us / 1e3))
+        tab.sort(reverse=True)
+        lines.append('')
+        lines.append('| kernel (all launches of that name) | launches | avg us | HBM MB / launch (2*FETCH+WRITE) | GB/s | of 8 TB/s |')
+        lines.append('|---|---|---|---|---|---|')
+        for _, k, n, us, by, gbs in tab[:24]:
+            lines.append('| `%s` | %d | %.1f | %.1f | %.0f | %.2f |' % (k, n, us, by / 1e6, gbs, gbs / 8000.0))
+        out['per_kernel_hbm'] = [{'kernel': k, 'launches': n, 'avg_us': us, 'bytes_per_launch': by, 'GBps': gbs} for _, k, n, us, by, gbs in tab]
     os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
     if len(sys.argv) > 3 and 'conv_igemm_clstm_bytes_per_launch' in out:      # the file bench.py reads `traffic` from
         json.dump({'conv_igemm_clstm_bytes_per_launch': out['conv_igemm_clstm_bytes_per_launch'],
