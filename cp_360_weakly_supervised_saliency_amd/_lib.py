@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 205
+ABI_VERSION = 206
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -35,7 +35,7 @@ SYMBOLS = [
     'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits',
     'cp360_conv_pack_weights', 'cp360_conv_pack_weights2', 'cp360_conv_forward', 'cp360_conv_forward2',
     'cp360_conv_finish',
-    'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_window_minmax',
+    'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_lstm_gates_next', 'cp360_window_minmax',
     'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes', 'cp360_band3x3_pack_weights', 'cp360_band3x3_forward',
     'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1', 'cp360_l1block_forward',
     'cp360_l2block_packed_bytes', 'cp360_l2block_pack_weights', 'cp360_l2block_forward',
@@ -95,6 +95,7 @@ def lib():
     L.cp360_conv_finish.argtypes = [pd, vp, vp, vp, vp, vp]
     L.cp360_cubepad_maxpool3s2.argtypes = [vp, vp, i, i, i, i, vp]
     L.cp360_lstm_gates.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, i, vp]
+    L.cp360_lstm_gates_next.argtypes = [vp, i, vp, vp, vp, vp, i, i, i, vp, i, i, i, vp, vp, i, i, sz, vp]
     L.cp360_window_minmax.argtypes = [vp, vp, vp, i, sz, sz, vp]
     L.cp360_window_normalize.argtypes = [vp, vp, vp, i, i, i, vp, i, i, i, i, i, sz, vp]
     L.cp360_resize_ksize.argtypes = [i, i]

@@ -179,6 +179,8 @@ __device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
     for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
 }
 
+// (Requesting the residual pieces BEFORE the K loop of the short-K kernel was tried: the 16-32 extra registers spill
+// under its 128-VGPR budget and the launch got 40 % slower - layer3 conv3 110 -> 155 us.)
 template <typename T, int MJ>
 __device__ __forceinline__ void epilogue_direct(const ConvK& p, f32x4 (&acc)[4][MJ], int n0, int m0, int wch0, int wrow0,
                                                 int lane, int rows_valid) {
@@ -1504,7 +1506,10 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ c_prev, float* __restrict__ c_next,
                                                          T* __restrict__ h_out, int ld_h, int h_coff,
-                                                         float* __restrict__ h_f32, int M, int Hc, int slab_rows) {
+                                                         float* __restrict__ h_f32, int M, int Hc, int slab_rows,
+                                                         const float* __restrict__ x_next,
+                                                         const float* __restrict__ minmax, int x_coff, int P,
+                                                         size_t clip_stride) {
     const int q = Hc >> 2, G = 4 * Hc;
     const long long total = (long long)M * q;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1538,6 +1543,13 @@ __global__ __launch_bounds__(256) void lstm_gates_kernel(const float* __restrict
         *reinterpret_cast<float4*>(c_next + (size_t)m * Hc + j) = make_float4(cn[0], cn[1], cn[2], cn[3]);
         store4(h_out + (size_t)m * ld_h + h_coff + j, hn);
         if (h_f32) *reinterpret_cast<float4*>(h_f32 + (size_t)m * Hc + j) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (x_next) {   // the NEXT step's input frame, window-normalised (test_temporal.py:77), into the x half of the same pixel
+            const int b = m / P, pix = m - b * P;
+            const float mn = minmax[2 * b], den = minmax[2 * b + 1] - mn;
+            const float4 v = *reinterpret_cast<const float4*>(x_next + (size_t)b * clip_stride + (size_t)pix * Hc + j);
+            const float xn[4] = {(v.x - mn) / den, (v.y - mn) / den, (v.z - mn) / den, (v.w - mn) / den};
+            store4(h_out + (size_t)m * ld_h + x_coff + j, xn);
+        }
     }
 }
 
@@ -1976,7 +1988,18 @@ extern "C" int cp360_conv_finish(const cp360_conv_desc* d, const float* partial,
 extern "C" int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias, const float* c_prev,
                                 float* c_next, void* h_out, int h_dtype, int ld_h, int h_coff, float* h_f32, int M,
                                 int Hc, int slab_rows, void* stream) {
+    return cp360_lstm_gates_next(gates_partial, splits, bias, c_prev, c_next, h_out, h_dtype, ld_h, h_coff, h_f32, M, Hc,
+                                 slab_rows, nullptr, nullptr, 0, 0, 0, stream);
+}
+
+extern "C" int cp360_lstm_gates_next(const float* gates_partial, int splits, const float* bias, const float* c_prev,
+                                     float* c_next, void* h_out, int h_dtype, int ld_h, int h_coff, float* h_f32, int M,
+                                     int Hc, int slab_rows, const float* x_next, const float* minmax, int x_coff,
+                                     int P, size_t clip_stride, void* stream) {
     if (!gates_partial || !bias || !c_prev || !c_next || !h_out) return CP360_ERR_NULL;
+    if (x_next && (!minmax || P <= 0 || M % P != 0 || x_coff % 4 != 0 || clip_stride % 4 != 0 || x_coff + Hc > ld_h ||
+                   (x_coff < h_coff + Hc && h_coff < x_coff + Hc)))
+        return CP360_ERR_BAD_SHAPE;
     if (splits < 1 || M <= 0 || Hc <= 0) return CP360_ERR_BAD_SHAPE;
     if (Hc % 4 != 0 || ld_h % 4 != 0 || h_coff % 4 != 0) return CP360_ERR_ALIGN;
     if (slab_rows && (4 * Hc) % 32 != 0) return CP360_ERR_ALIGN;
@@ -1986,13 +2009,15 @@ extern "C" int cp360_lstm_gates(const float* gates_partial, int splits, const fl
     hipStream_t st = (hipStream_t)stream;
     if (h_dtype == CP360_F32)
         hipLaunchKernelGGL((lstm_gates_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial, splits,
-                           bias, c_prev, c_next, (float*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows);
+                           bias, c_prev, c_next, (float*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows, x_next, minmax, x_coff, P, clip_stride);
     else if (h_dtype == CP360_BF16)
         hipLaunchKernelGGL((lstm_gates_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
-                           splits, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows);
+                           splits, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows, x_next, minmax, x_coff, P,
+                           clip_stride);
     else if (h_dtype == CP360_F16)
         hipLaunchKernelGGL((lstm_gates_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, gates_partial,
-                           splits, bias, c_prev, c_next, (f16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows);
+                           splits, bias, c_prev, c_next, (f16_raw*)h_out, ld_h, h_coff, h_f32, M, Hc, slab_rows, x_next, minmax, x_coff, P,
+                           clip_stride);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

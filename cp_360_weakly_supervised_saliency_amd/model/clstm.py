@@ -74,12 +74,13 @@ class ConvLSTMCell(nn.Module):
             self._plan_stamp = stamp
         return self._plan
 
-    def step_nhwc(self, xh, c_prev, c_next, h_f32=None, bufs=None):
+    def step_nhwc(self, xh, c_prev, c_next, h_f32=None, bufs=None, x_next=None):
         """One cell update on the fused layout.
         xh     [6B, w, w, Cin+Ch]  compute dtype: channels [0, Cin) = input frame,
                [Cin, Cin+Ch) = previous hidden; the NEW hidden is written back into
                the hidden half (ready for the next step)
         c_prev / c_next [6B, w, w, Ch] f32; h_f32 optional f32 copy of the new hidden.
+        x_next (ClipRunner): the next frame's window normalisation rides on the gate kernel (needs Cin == Ch).
         """
         p = self.plans()
         n6, w, _, _ = xh.shape
@@ -87,8 +88,10 @@ class ConvLSTMCell(nn.Module):
         a2 = p['c2'](a1, out=None if bufs is None else bufs[1])
         sr = (4 * self.hidden_size) % 32 == 0              # gate slabs in packed-row order (64-byte stores)
         partial, splits = p['g'](a2, raw_f32=True, slab_rows=sr)
+        # x_next = (cam, minmax, P, clip_stride, t_next): the gate kernel also writes the next step's normalised input
+        xn = None if x_next is None else (x_next[0], x_next[1], 0, x_next[2], x_next[3], x_next[4])
         ops.lstm_gates(partial, splits, p['gbias'], c_prev, c_next, xh, self.input_size, h_f32,
-                       n6 * w * w, self.hidden_size, slab_rows=sr)
+                       n6 * w * w, self.hidden_size, slab_rows=sr, x_next=xn)
 
     def forward(self, input_, prev_state=None):
         """input_ [6B, Cin, w, w]; prev_state = (hidden, cell) [6B, Ch, w, w] or None

@@ -531,7 +531,9 @@ def cubepad_maxpool3s2(x):
     return y
 
 
-def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, Hc, slab_rows=False):
+def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, Hc, slab_rows=False, x_next=None):
+    """model/clstm.py:68-80.  ``x_next`` = (cam, minmax, x_coff, P, clip_stride, t_next): also write the window-
+    normalised frame t_next of every clip into channels [x_coff, x_coff + Hc) of ``h_out`` (the next step's input)."""
     require_gpu(partial, bias, c_prev, c_next, h_out, h_f32)
     _check_buf('gates partial', partial, torch.float32, numel=splits * M * 4 * Hc)
     _check_buf('gates bias', bias, torch.float32, numel=4 * Hc)
@@ -540,6 +542,16 @@ def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, H
     _check_buf('h_f32', h_f32, torch.float32, numel=M * Hc)
     if not h_out.is_contiguous() or h_out.numel() < M * h_out.shape[-1] or h_coff + Hc > h_out.shape[-1]:
         raise ValueError("h_out must be contiguous [.., ld] with M pixels and h_coff + Hc <= ld")
+    if x_next is not None:
+        cam, minmax, x_coff, P, clip_stride, t_next = x_next
+        require_gpu(cam, minmax)
+        _check_buf('cam', cam, torch.float32, numel=(M // P - 1) * clip_stride + (t_next + 1) * P * Hc)
+        _check_buf('minmax', minmax, torch.float32, numel=2 * (M // P))
+        xp = C.c_void_p(cam.data_ptr() + 4 * t_next * P * Hc)
+        check(lib().cp360_lstm_gates_next(ptr(partial), splits, ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out),
+                                          dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc,
+                                          int(slab_rows), xp, ptr(minmax), x_coff, P, clip_stride, stream()))
+        return
     check(lib().cp360_lstm_gates(ptr(partial), splits, ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out),
                                  dtype_code(h_out.dtype), h_out.shape[-1], h_coff, ptr(h_f32), M, Hc,
                                  int(slab_rows), stream()))

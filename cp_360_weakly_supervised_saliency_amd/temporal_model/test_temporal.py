@@ -44,10 +44,13 @@ class ClipRunner:
         # hidden = cell = (frame0 - mn) / (mx - mn)
         ops.window_normalize(cam, self.minmax, self.xh, cin, self.c[0], B, T, 0, P, cin, stride)
         cur = 0
+        per_clip = stride if sliding else T * P * cin
+        ops.window_normalize(cam, self.minmax, self.xh, 0, None, B, T, 0, P, cin, stride)
         for t in range(T):
-            ops.window_normalize(cam, self.minmax, self.xh, 0, None, B, T, t, P, cin, stride)
+            # frame t+1's normalisation rides on step t's gate kernel (its x half of xh is free by then)
+            nxt = (cam, self.minmax, P, per_clip, t + 1) if t + 1 < T else None
             self.cell.step_nhwc(self.xh, self.c[cur], self.c[cur ^ 1],
-                                self.h_f32 if t == T - 1 else None, bufs=self.a)
+                                self.h_f32 if t == T - 1 else None, bufs=self.a, x_next=nxt)
             cur ^= 1
         sal = self.c2e.saliency(self.h_f32, layout='nhwc')
         return (sal, self.h_f32) if return_hidden else sal

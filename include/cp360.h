@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 205
+#define CP360_VERSION 206
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -315,6 +315,15 @@ int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, int C, int d
 int cp360_lstm_gates(const float* gates_partial, int splits, const float* bias,
                      const float* c_prev, float* c_next, void* h_out, int h_dtype,
                      int ld_h, int h_coff, float* h_f32, int M, int Hc, int slab_rows, void* stream);
+/* The same plus the NEXT step's input: x_next f32 (frame t+1 of clip 0; clip b at + b*clip_stride elements,
+ * pixel-major [P, Hc]) is window-normalised with minmax [M/P, 2] (test_temporal.py:77) and written to
+ * h_out[m*ld_h + x_coff + j] - the x half of the ConvLSTM's concatenated input - in the same pass (one launch per
+ * step less).  Needs input_size == Hc.  x_next == NULL: plain cp360_lstm_gates. */
+int cp360_lstm_gates_next(const float* gates_partial, int splits, const float* bias,
+                          const float* c_prev, float* c_next, void* h_out, int h_dtype,
+                          int ld_h, int h_coff, float* h_f32, int M, int Hc, int slab_rows,
+                          const float* x_next, const float* minmax, int x_coff, int P, size_t clip_stride,
+                          void* stream);
 
 /* ------------------------------------------------------------------ K7: window normalise
  * temporal_model/test_temporal.py:66-67,70-73,77: per clip min / max over the whole
