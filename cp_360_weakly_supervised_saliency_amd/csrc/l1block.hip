@@ -1,4 +1,4 @@
-// K3d: one whole Bottleneck tail of layer1 in ONE kernel (16-bit types, 56x56 cube faces):
+// K3d: one whole Bottleneck tail of layer1 in ONE kernel (16-bit types; 56x56 faces = cube 224, 128x128 = cube 512):
 //
 //   mid  --CubePad(1)+conv3x3 64->64 +bn2+relu-->  t  --conv1x1 64->256 +bn3 (+ residual | + downsample(x)) +relu-->  out
 //                                                        `--(optional) next block's conv1x1 256->64 +bn1+relu-->  mid'
@@ -7,7 +7,8 @@
 // Run as separate launches these are HBM-bound (layer1 = 1.9 of the static stage's 7 ms) and every
 // tensor between them makes a round trip through HBM: t (154 MB for 64 frames) twice, out (616 MB) written by conv3
 // and read again by the next conv1.  Here a workgroup owns a band of 4 output rows of one face, as band3x3.hip:
-//   stage 1  conv2 exactly as band3x3_kernel (resident cube-padded band in LDS, nine taps read it there);
+//   stage 1  conv2 as band3x3_kernel (resident cube-padded band in LDS, nine taps read it there), its weights as MFMA
+//            A fragments straight from L2 into registers two taps ahead (no LDS ring, no barrier in the stage);
 //   stage 2  the conv2 accumulators ARE the next MFMA's B operand: with the acc_chan row order of the packed
 //            weights a lane ends with EIGHT consecutive channels of one pixel per pair of MFMA row blocks - the
 //            k-group layout of a 16x16x32 B fragment.  bias + ReLU + one rounding and the packed 16 bytes feed conv3
@@ -29,16 +30,23 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
-constexpr int N = 56, NP = N + 2, C = 64, CO = 256, BAND = 4;
-constexpr int PATCH_PX = (BAND + 2) * NP;                    // 348
-constexpr int PATCH_INST = (PATCH_PX + 7) / 8;               // 44 DMA instructions of 8 pixels x 128 B
-constexpr int PATCH_LDS = PATCH_INST * 1024;                 // 45,056
-constexpr int W_TAP = 64 * 128;                              // 8 KiB: one tap's 64 rows x 64 channels
-constexpr int W_SLOTS = 3;
-constexpr int LDS_BYTES = PATCH_LDS + W_SLOTS * W_TAP;       // 69,632: two workgroups per CU
+constexpr int C = 64, CO = 256;
+constexpr int W2_TAP = 8 * 1024;                             // conv2: 8 fragments (4 row blocks x 2 k-blocks) per tap
 constexpr int W3_BYTES = CO * C * 2;                         // 32 KiB of conv3 fragments
 constexpr int W1_BYTES = C * CO * 2;                         // 32 KiB of next-conv1 fragments
-static_assert(W3_BYTES + W1_BYTES + (CO + C) * 4 <= LDS_BYTES, "stage-3 weights must fit the LDS of stage 1");
+constexpr int STAGE3_LDS = W3_BYTES + W1_BYTES + (CO + C) * 4;
+// Face size N, BAND output rows per workgroup (4 waves): 56x56 faces (cube 224) -> 4 rows, wave = row (64 pixel slots,
+// 8 of them padding); 128x128 faces (cube 512, BASELINE config C5) -> 2 rows, two waves per row (64 pixels each).
+template <int N_, int BAND_> struct L1Geom {
+    static constexpr int N = N_, BAND = BAND_, NP = N + 2, WPR = 4 / BAND;
+    static constexpr int PATCH_PX = (BAND + 2) * NP;                          // 348 / 520
+    static constexpr int PATCH_INST = (PATCH_PX + 7) / 8;                     // DMA instructions of 8 pixels x 128 B
+    static constexpr int PATCH_LDS = PATCH_INST * 1024;                       // 45,056 / 66,560
+    static constexpr int READ_END = ((BAND + 1) * NP + 2 + 64 * WPR) * 128;   // padding columns read past the patch
+    static constexpr int LDS_BYTES = (PATCH_LDS > READ_END ? PATCH_LDS : READ_END) > STAGE3_LDS
+                                         ? (PATCH_LDS > READ_END ? PATCH_LDS : READ_END) : STAGE3_LDS;   // 66,816: two per CU
+    static_assert(N % BAND == 0 && 64 * WPR >= N && 4 % BAND == 0, "band geometry");
+};
 
 __device__ __attribute__((aligned(16))) unsigned int l_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -55,7 +63,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 __device__ __forceinline__ int px_swz(int p) { return ((p >> 1) & 3) << 1; }
-__device__ __forceinline__ int w_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <typename T> __device__ __forceinline__ void mma(f32x4& acc, const u32x4& a, const u32x4& b);
 template <> __device__ __forceinline__ void mma<bf16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
@@ -94,6 +101,21 @@ __device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
 __host__ __device__ __forceinline__ int row_chan(int R) { return (R & ~31) + ((R >> 2) & 3) * 8 + ((R >> 4) & 1) * 4 + (R & 3); }
 }  // namespace
 
+// conv2 weights [64, 64, 3, 3] (times scale) -> MFMA A fragments [tap 9][row block 4][kk 2][lane][8]: lane l holds row
+// (l & 15) of the block (rows in acc_chan order), input channels kk*32 + (l>>4)*8 .. +7 of tap (ky, kx)
+template <typename T>
+__global__ __launch_bounds__(256) void l1_pack_conv2_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                            T* __restrict__ packed) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 9 * C * C) return;
+    const int e = idx & 7, lane = (idx >> 3) & 63, kk = (idx >> 9) & 1, rb = (idx >> 10) & 3, tap = idx >> 12;
+    const int n = row_chan(rb * 16 + (lane & 15));
+    const int c = kk * 32 + (lane >> 4) * 8 + e;
+    const float v = w[((size_t)n * C + c) * 9 + tap] * (scale ? scale[n] : 1.f);
+    if constexpr (__is_same(T, f16_raw)) packed[idx] = (f16_raw)v;
+    else packed[idx] = f32_to_bf16(v);
+}
+
 // 1x1 filter w [n_out, k] (times scale[n_out]) -> MFMA A fragments, 1 KiB each ([lane][8 elements]: lane l holds
 // row (l & 15), k-group (l >> 4) of the fragment), rows in acc_chan order.
 //   order 0 (row-pair major, for conv3 / downsample):  fragment ((p * 2 + rb) * KB + kb), p = 32-row pair
@@ -117,14 +139,16 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const float* __restrict_
     }
 }
 
-template <typename T, bool DS, bool NEXT>
+template <typename T, bool DS, bool NEXT, int NV, int BANDV>
 __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
                                                          const T* __restrict__ xds, const T* __restrict__ wdf,
                                                          T* __restrict__ out, const T* __restrict__ w1f,
                                                          const float* __restrict__ bias1, T* __restrict__ out_next) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    typedef L1Geom<NV, BANDV> G;
+    constexpr int N = G::N, NP = G::NP, BAND = G::BAND, WPR = G::WPR, PATCH_PX = G::PATCH_PX, PATCH_INST = G::PATCH_INST;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)lds;
@@ -132,9 +156,11 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     const int grp = img / 6, f = img - grp * 6;
     const CubePadGeom geom{N, 1, 1, 1, 1};
     const int lrow = lane & 15, lchunk = lane >> 4;
-    const size_t row_px = ((size_t)img * N + band * BAND + wave) * N;     // first pixel of this wave's output row
+    const int wrow = wave / WPR, x0 = (wave - wrow * WPR) * 64;               // this wave's output row and first column
+    const size_t row_px = ((size_t)img * N + band * BAND + wrow) * N + x0;    // its first pixel
 
-    // ---- stage 1: conv2 on the resident cube-padded band (band3x3.hip)
+    // ---- stage 1: conv2 on the resident cube-padded band (band3x3.hip), A fragments from L2 straight into
+    // registers two taps ahead: no weight ring in LDS and no barrier inside the stage (l2block.hip)
     {
         const T* xg = x + (size_t)grp * 6 * N * N * C;
 #pragma unroll 1
@@ -150,39 +176,34 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
         }
     }
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk2);
-    auto load_w = [&](int t, int s) __attribute__((always_inline)) {
+    auto load_a = [&](int t, u32x4 (&a)[4][2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int inst = wave * 2 + q;
-            const int row = inst * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            glds16(wb + (size_t)t * W_TAP + row * 128 + chunk * 16,
-                   __builtin_amdgcn_readfirstlane(lds_base + PATCH_LDS + s * W_TAP + inst * 1024));
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                a[i][kk] = *reinterpret_cast<const u32x4*>(wb + (size_t)t * W2_TAP + ((i * 2 + kk) * 64 + lane) * 16);
     };
-    load_w(0, 0);
-    load_w(1, 1);
+    constexpr int DEPTH = 2;
+    u32x4 aq[DEPTH + 1][4][2];
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) load_a(t, aq[t]);
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patch DMAs (and the first fragments)
+    __syncthreads();
 
-#pragma unroll 1
+#pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        if (tap < 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tap + 2 < 9) load_w(tap + 2, (tap + 2) % W_SLOTS);
+        if (tap + DEPTH < 9) load_a(tap + DEPTH, aq[(tap + DEPTH) % (DEPTH + 1)]);
         const int ky = tap / 3, kx = tap - ky * 3;
-        const unsigned char* Ws = lds + PATCH_LDS + (tap % W_SLOTS) * W_TAP;
-        const int pbase = (wave + ky) * NP + kx + lrow;
+        const int pbase = (wrow + ky) * NP + kx + x0 + lrow;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            u32x4 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(Ws + w_off(i * 16 + lrow, kk * 4 + lchunk));
+            u32x4 b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int p = pbase + 16 * j;
@@ -191,10 +212,11 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], aq[tap % (DEPTH + 1)][i][kk], b[j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // every wave is done with the patch and the weight ring: bring conv3's (and the next conv1's) fragments in
+    // every wave is done with the patch: bring conv3's (and the next conv1's) fragments in
     __syncthreads();
     {
         const unsigned char* s3 = reinterpret_cast<const unsigned char*>(w3f);
@@ -236,10 +258,10 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     if (DS) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int xo = j * 16 + lrow;
+            const int xo = x0 + j * 16 + lrow;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const T* src = xo < N ? xds + (row_px + xo) * C + kb * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
+                const T* src = xo < N ? xds + (row_px + j * 16 + lrow) * C + kb * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
                 bx[kb][j] = *reinterpret_cast<const u32x4*>(src);
             }
         }
@@ -253,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     auto load_res = [&](int p, u32x4 (&r)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int xo = j * 16 + lrow;
-            const T* src = xo < N ? res + (row_px + xo) * CO + p * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
+            const int xo = x0 + j * 16 + lrow;
+            const T* src = xo < N ? res + (row_px + j * 16 + lrow) * CO + p * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
             r[j] = *reinterpret_cast<const u32x4*>(src);
         }
     };
@@ -336,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             o[j] = pack8(v, T());
-            const int xo = j * 16 + lrow;
-            if (xo < N) *reinterpret_cast<u32x4*>(out + (row_px + xo) * CO + n) = o[j];
+            const int xo = x0 + j * 16 + lrow;
+            if (xo < N) *reinterpret_cast<u32x4*>(out + (row_px + j * 16 + lrow) * CO + n) = o[j];
         }
         if (NEXT) {     // out's channels 32p .. 32p+31 = k-block p of the next conv1
             u32x4 a1[4];
@@ -372,14 +394,14 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
             for (int e = 0; e < 8; ++e) bb[e] = bias_s[CO + n + e];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int xo = j * 16 + lrow;
+                const int xo = x0 + j * 16 + lrow;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = fmaxf(acc[2 * pr][j][e] + bb[e], 0.f);
                     v[4 + e] = fmaxf(acc[2 * pr + 1][j][e] + bb[4 + e], 0.f);
                 }
-                if (xo < N) *reinterpret_cast<u32x4*>(orow + (size_t)xo * C + n) = pack8(v, T());
+                if (xo < N) *reinterpret_cast<u32x4*>(orow + (size_t)(j * 16 + lrow) * C + n) = pack8(v, T());
             }
         }
     }
@@ -406,6 +428,24 @@ extern "C" int cp360_frag_pack_1x1(int dtype, const float* w, const float* scale
     return CP360_OK;
 }
 
+extern "C" size_t cp360_l1block_conv2_bytes(int dtype) {
+    return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)9 * W2_TAP : 0;
+}
+
+extern "C" int cp360_l1block_pack_conv2(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
+    if (!w_oihw || !packed) return CP360_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (9 * C * C + 255) / 256;
+    if (dtype == CP360_BF16)
+        hipLaunchKernelGGL((l1_pack_conv2_kernel<bf16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (bf16_raw*)packed);
+    else if (dtype == CP360_F16)
+        hipLaunchKernelGGL((l1_pack_conv2_kernel<f16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (f16_raw*)packed);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
 extern "C" int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
                                      const void* w3_frags, const float* bias3, const void* residual, const void* x_ds,
                                      const void* wd_frags, void* out, const void* w1_frags, const float* bias1,
@@ -416,25 +456,26 @@ extern "C" int cp360_l1block_forward(int dtype, const void* mid, const void* w2_
     if ((w1_frags != nullptr) != (out_next != nullptr)) return CP360_ERR_NULL;
     if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
     if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
-    if (face != N) return CP360_ERR_UNSUPPORTED;                                  // other sizes: the per-convolution path
-    if ((long long)n_img * N * N * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    if (face != 56 && face != 128) return CP360_ERR_UNSUPPORTED;                  // other sizes: the per-convolution path
+    if ((long long)n_img * face * face * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)(n_img * (N / BAND)));
-#define CP360_L1B(TT, DSV, NX)                                                                                  \
-    hipLaunchKernelGGL((l1block_kernel<TT, DSV, NX>), grid, dim3(256), 0, st, (const TT*)mid, (const TT*)w2_packed, \
-                       bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (const TT*)x_ds, (const TT*)wd_frags, \
-                       (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next)
-#define CP360_L1B_T(TT)                                         \
+#define CP360_L1B(TT, DSV, NX, NV, BV)                                                                          \
+    hipLaunchKernelGGL((l1block_kernel<TT, DSV, NX, NV, BV>), dim3((unsigned)(n_img * (NV / BV))), dim3(256), 0, st, \
+                       (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, \
+                       (const TT*)x_ds, (const TT*)wd_frags, (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next)
+#define CP360_L1B_F(TT, NV, BV)                                 \
     {                                                           \
-        if (x_ds && w1_frags) CP360_L1B(TT, true, true);        \
-        else if (x_ds) CP360_L1B(TT, true, false);              \
-        else if (w1_frags) CP360_L1B(TT, false, true);          \
-        else CP360_L1B(TT, false, false);                       \
+        if (x_ds && w1_frags) CP360_L1B(TT, true, true, NV, BV);  \
+        else if (x_ds) CP360_L1B(TT, true, false, NV, BV);        \
+        else if (w1_frags) CP360_L1B(TT, false, true, NV, BV);    \
+        else CP360_L1B(TT, false, false, NV, BV);                 \
     }
+#define CP360_L1B_T(TT) { if (face == 56) CP360_L1B_F(TT, 56, 4) else CP360_L1B_F(TT, 128, 2) }
     if (dtype == CP360_BF16) CP360_L1B_T(bf16_raw)
     else if (dtype == CP360_F16) CP360_L1B_T(f16_raw)
     else return CP360_ERR_BAD_DTYPE;
 #undef CP360_L1B_T
+#undef CP360_L1B_F
 #undef CP360_L1B
     CP360_CHECK_HIP();
     return CP360_OK;

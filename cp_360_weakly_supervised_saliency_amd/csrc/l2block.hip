@@ -1,4 +1,4 @@
-// K3e: the tail of a layer2 identity Bottleneck in ONE kernel (16-bit types, 28x28 cube faces):
+// K3e: the tail of a layer2 identity Bottleneck in ONE kernel (16-bit types; 28x28 faces = cube 224, 64x64 = cube 512):
 //
 //   mid [.,28,28,128] --CubePad(1)+conv3x3 128->128 +bn2+relu--> t --conv1x1 128->512 +bn3 + residual + relu--> out
 //
@@ -27,19 +27,22 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
-constexpr int N = 28, NP = N + 2, C = 128, CO = 512, BAND = 4;
-constexpr int PX = BAND * N;                                 // 112 output pixels per band = 7 blocks of 16
-constexpr int PB = PX / 16;                                  // 7
-constexpr int PATCH_PX = (BAND + 2) * NP;                    // 180
-constexpr int PATCH_INST = PATCH_PX / 4;                     // 45 DMA instructions of 4 pixels x 256 B
-constexpr int PATCH_LDS = PATCH_INST * 1024;                 // 46,080
+constexpr int C = 128, CO = 512;
 constexpr int W_STEP = C * 128;                              // 16 KiB of conv2 weights per half tap (16 fragments)
-template <int NB> struct L2Geom {                            // NB = bands per workgroup (4 waves each)
-    static constexpr int OFF_BIAS = NB * PATCH_LDS;
-    static constexpr int LDS_BYTES = OFF_BIAS + (C + CO) * 4; // 48,640 (NB = 1: two workgroups per CU) / 94,720
-};
 constexpr int T_STRIDE = C * 2 + 16;                         // 272-byte pixel stride of the t tile
-static_assert(PX * T_STRIDE <= PATCH_LDS, "the t tile reuses its band's patch");
+// Face size N, BAND output rows per band (4 waves): 28x28 faces (cube 224) -> 4 rows = 112 pixels = 7 pixel blocks;
+// 64x64 faces (cube 512, BASELINE config C5) -> 2 rows = 128 pixels = 8 blocks.  NB = bands per workgroup.
+template <int N_, int BAND_, int NB> struct L2Geom {
+    static constexpr int N = N_, BAND = BAND_, NP = N + 2;
+    static constexpr int PX = BAND * N;                      // output pixels per band (consecutive in memory)
+    static constexpr int PB = PX / 16;
+    static constexpr int PATCH_PX = (BAND + 2) * NP;         // 180 / 264
+    static constexpr int PATCH_INST = PATCH_PX / 4;          // DMA instructions of 4 pixels x 256 B
+    static constexpr int PATCH_LDS = PATCH_INST * 1024;      // 46,080 / 67,584
+    static constexpr int OFF_BIAS = NB * PATCH_LDS;
+    static constexpr int LDS_BYTES = OFF_BIAS + (C + CO) * 4;
+    static_assert(PX % 16 == 0 && PATCH_PX % 4 == 0 && N % BAND == 0 && PX * T_STRIDE <= PATCH_LDS, "band geometry");
+};
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -107,13 +110,15 @@ __global__ __launch_bounds__(256) void l2_pack_kernel(const float* __restrict__ 
     else packed[idx] = f32_to_bf16(v);
 }
 
-template <typename T, int NB>
+template <typename T, int NB, int NV, int BANDV>
 __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
                                                          T* __restrict__ out) {
-    constexpr int OFF_BIAS = L2Geom<NB>::OFF_BIAS;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[L2Geom<NB>::LDS_BYTES];
+    typedef L2Geom<NV, BANDV, NB> G;
+    constexpr int N = G::N, NP = G::NP, BAND = G::BAND, PX = G::PX, PB = G::PB, PATCH_INST = G::PATCH_INST,
+                  PATCH_LDS = G::PATCH_LDS, OFF_BIAS = G::OFF_BIAS;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half_wg = wave >> 2, w4 = wave & 3;              // band A / B of this workgroup, wave inside the band
@@ -302,17 +307,23 @@ extern "C" int cp360_l2block_forward(int dtype, const void* mid, const void* w2_
     if (!mid || !w2_packed || !w3_frags || !bias3 || !residual || !out) return CP360_ERR_NULL;
     if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
     if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
-    if (face != N) return CP360_ERR_UNSUPPORTED;
-    if ((long long)n_img * N * N * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    if (face != 28 && face != 64) return CP360_ERR_UNSUPPORTED;
+    if ((long long)n_img * face * face * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     static const int nb_env = []() { const char* e = getenv("CP360_L2_BANDS"); return e ? atoi(e) : 1; }();   // A/B switch
-    const int nb = nb_env == 2 ? 2 : 1;
-    const dim3 grid((unsigned)(n_img * (N / BAND) / nb));      // n_img % 6 == 0: an even number of bands
-#define CP360_L2B(TT, NBV)                                                                                       \
-    hipLaunchKernelGGL((l2block_kernel<TT, NBV>), grid, dim3(256 * NBV), 0, st, (const TT*)mid, (const TT*)w2_packed, \
-                       bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out)
-    if (dtype == CP360_BF16) { if (nb == 2) CP360_L2B(bf16_raw, 2); else CP360_L2B(bf16_raw, 1); }
-    else if (dtype == CP360_F16) { if (nb == 2) CP360_L2B(f16_raw, 2); else CP360_L2B(f16_raw, 1); }
+    const int nb = (nb_env == 2 && face == 28) ? 2 : 1;
+#define CP360_L2B(TT, NBV, NV, BV)                                                                               \
+    hipLaunchKernelGGL((l2block_kernel<TT, NBV, NV, BV>), dim3((unsigned)(n_img * (NV / BV) / NBV)), dim3(256 * NBV), 0, st, \
+                       (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out)
+#define CP360_L2B_T(TT)                                      \
+    {                                                        \
+        if (face == 64) CP360_L2B(TT, 1, 64, 2);             \
+        else if (nb == 2) CP360_L2B(TT, 2, 28, 4);           \
+        else CP360_L2B(TT, 1, 28, 4);                        \
+    }
+    if (dtype == CP360_BF16) CP360_L2B_T(bf16_raw)
+    else if (dtype == CP360_F16) CP360_L2B_T(f16_raw)
+#undef CP360_L2B_T
 #undef CP360_L2B
     else
         return CP360_ERR_BAD_DTYPE;

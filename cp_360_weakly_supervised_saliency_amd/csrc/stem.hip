@@ -1,6 +1,6 @@
 // K3a: the ResNet stem, CubePad(3) -> conv 7x7 stride 2 (3 -> 64) + BN + ReLU
-// (model/resnet_cubic.py:115-128,163-168), as a resident-patch MFMA kernel for 16-bit types at the
-// reference's cube size (224: padded faces 230x230, output 112x112).
+// (model/resnet_cubic.py:115-128,163-168), as a resident-patch MFMA kernel for 16-bit types at cube sizes 224 (the
+// reference's: padded faces 230x230, output 112x112) and 512 (BASELINE config C5: 518x518 -> 256x256).
 //
 // The generic implicit GEMM treats the 7x7 filter as 7 taps of 8 pixels x 4 channels and re-gathers a
 // 64-byte im2col row per output pixel and tap: 4.2 GB through the L2 -> LDS path for 64 frames, which
@@ -22,13 +22,22 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
-constexpr int CD = 224, WP = CD + 6, WO = CD / 2;            // padded input width, output width
-constexpr int ROW_BYTES = WP * 8;                            // 1840: one padded input row (4 x 16-bit per pixel)
-constexpr int BAND = 8, PATCH_ROWS = 2 * (BAND - 1) + 7;     // 21 input rows per band of 8 output rows
-constexpr int PATCH_BYTES = PATCH_ROWS * ROW_BYTES;          // 38,640
-constexpr int PATCH_LDS = 38 * 1024;                         // DMA granule: 38 x 1 KiB
+// Geometry per cube size.  BAND output rows per workgroup, WPR waves per output row (8 waves in all): cube 224 ->
+// 8 rows x 112 pixels (7 pixel blocks per wave); cube 512 (BASELINE config C5) -> 4 rows x 256 pixels, two waves per
+// row (8 pixel blocks each: the accumulators of a whole 256-pixel row would not fit a wave's registers).
+template <int CD_> struct StemGeom {
+    static constexpr int CD = CD_, WP = CD + 6, WO = CD / 2;      // padded input width, output width
+    static constexpr int ROW_BYTES = WP * 8;                      // one padded input row (4 x 16-bit per pixel)
+    static constexpr int WPR = CD == 224 ? 1 : 2;
+    static constexpr int BAND = 8 / WPR;
+    static constexpr int PATCH_ROWS = 2 * (BAND - 1) + 7;         // 21 (13) input rows per band
+    static constexpr int PATCH_BYTES = PATCH_ROWS * ROW_BYTES;    // 38,640 (53,872)
+    static constexpr int PATCH_INST = (PATCH_BYTES + 1023) / 1024;
+    static constexpr int PATCH_LDS = PATCH_INST * 1024;           // DMA granule: 1 KiB
+    static constexpr int MJ = WO / 16 / WPR;                      // 7 (8) pixel blocks per wave
+    static_assert(WO % (16 * WPR) == 0 && WO % BAND == 0, "cube size");
+};
 constexpr int W_BYTES = 7 * 64 * 64;                         // [ky][64 rows][32 k] 16-bit
-constexpr int MJ = WO / 16;                                  // 7 pixel blocks per output row
 
 __device__ __attribute__((aligned(16))) unsigned int s_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -86,10 +95,13 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
     else packed[idx] = f32_to_bf16(v);
 }
 
-template <typename T>
+template <typename T, int CDV>
 __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, const T* __restrict__ wpk,
                                                       const float* __restrict__ bias, T* __restrict__ out, int n_img,
                                                       int relu) {
+    typedef StemGeom<CDV> G;
+    constexpr int WP = G::WP, WO = G::WO, ROW_BYTES = G::ROW_BYTES, BAND = G::BAND, PATCH_BYTES = G::PATCH_BYTES,
+                  PATCH_LDS = G::PATCH_LDS, PATCH_INST = G::PATCH_INST, MJ = G::MJ, WPR = G::WPR;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[W_BYTES + 2 * PATCH_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,15 +110,15 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(xp);
     const size_t img_bytes = (size_t)WP * ROW_BYTES;
 
-    // patch of tile t -> buffer b: 38 DMA instructions of 1 KiB, wave w issues w, w+8, ...; the bytes
-    // past the 38,640 of the patch come from a zero line (never read by the MFMAs)
+    // patch of tile t -> buffer b: PATCH_INST DMA instructions of 1 KiB, wave w issues w, w+8, ...; the bytes
+    // past the patch's end come from a zero line (never read by the MFMAs)
     auto load_patch = [&](int t, int b) __attribute__((always_inline)) {
         const int img = t / (WO / BAND), band = t - img * (WO / BAND);
         const unsigned char* src0 = xb + (size_t)img * img_bytes + (size_t)(2 * BAND * band) * ROW_BYTES;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < (PATCH_INST + 7) / 8; ++q) {
             const int inst = wave + 8 * q;
-            if (inst < 38) {
+            if (inst < PATCH_INST) {
                 const int off = inst * 1024 + lane * 16;
                 const void* src = off < PATCH_BYTES ? (const void*)(src0 + off) : (const void*)s_zero16;
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_base + W_BYTES + b * PATCH_LDS + inst * 1024));
@@ -130,11 +142,14 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
     if (t < ntiles) load_patch(t, 0);
 
     const int lrow = lane & 15, lchunk = lane >> 4;
+    constexpr bool BIAS_REGS = MJ <= 7;      // the 8-block variant has no registers to spare: its biases are re-read per band
     float bb[2][8];
+    if (BIAS_REGS) {
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
+        for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bb[pr][e] = bias ? bias[pr * 32 + (lane >> 4) * 8 + e] : 0.f;
+            for (int e = 0; e < 8; ++e) bb[pr][e] = bias ? bias[pr * 32 + (lane >> 4) * 8 + e] : 0.f;
+    }
 
     int buf = 0;
     for (; t < ntiles; t += gridDim.x, buf ^= 1) {
@@ -147,7 +162,8 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const unsigned char* P = lds + W_BYTES + buf * PATCH_LDS + (2 * wave) * ROW_BYTES + 16 * (lrow + lchunk);
+        const int wrow = wave / WPR, col0 = (wave - wrow * WPR) * (MJ * 16);    // this wave's output row and first column
+        const unsigned char* P = lds + W_BYTES + buf * PATCH_LDS + (2 * wrow) * ROW_BYTES + 16 * (col0 + lrow + lchunk);
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
             u32x4 a[4], b[MJ];
@@ -163,17 +179,20 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
         }
         // epilogue: output row (band*8 + wave) of image img
         const int img = t / (WO / BAND), band = t - img * (WO / BAND);
-        T* orow = out + ((size_t)img * WO + band * BAND + wave) * WO * 64;
+        T* orow = out + (((size_t)img * WO + band * BAND + wrow) * WO + col0) * 64;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
             const int n = pr * 32 + (lane >> 4) * 8;
+            float bl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bl[e] = BIAS_REGS ? bb[pr][e] : (bias ? bias[n + e] : 0.f);
 #pragma unroll
             for (int j = 0; j < MJ; ++j) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[2 * pr][j][e] + bb[pr][e];
-                    v[4 + e] = acc[2 * pr + 1][j][e] + bb[pr][4 + e];
+                    v[e] = acc[2 * pr][j][e] + bl[e];
+                    v[4 + e] = acc[2 * pr + 1][j][e] + bl[4 + e];
                 }
                 if (relu) {
 #pragma unroll
@@ -206,17 +225,18 @@ extern "C" int cp360_stem_forward(int dtype, const void* xp, const void* packed,
                                   int cube_dim, int relu, void* stream) {
     if (!xp || !packed || !out) return CP360_ERR_NULL;
     if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
-    if (cube_dim != CD) return CP360_ERR_UNSUPPORTED;           // other cube sizes: the generic implicit GEMM
-    if ((long long)n_img * WP * ROW_BYTES >= (1LL << 40)) return CP360_ERR_BAD_SHAPE;
+    if (cube_dim != 224 && cube_dim != 512) return CP360_ERR_UNSUPPORTED;   // other cube sizes: the generic implicit GEMM
     hipStream_t st = (hipStream_t)stream;
-    const int ntiles = n_img * (WO / BAND);
-    const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
-    if (dtype == CP360_BF16)
-        hipLaunchKernelGGL((stem_kernel<bf16_raw>), grid, dim3(512), 0, st, (const bf16_raw*)xp, (const bf16_raw*)packed,
-                           bias, (bf16_raw*)out, n_img, relu);
-    else if (dtype == CP360_F16)
-        hipLaunchKernelGGL((stem_kernel<f16_raw>), grid, dim3(512), 0, st, (const f16_raw*)xp, (const f16_raw*)packed,
-                           bias, (f16_raw*)out, n_img, relu);
+#define CP360_STEM(TT, CDV)                                                                                     \
+    {                                                                                                           \
+        const int ntiles = n_img * (StemGeom<CDV>::WO / StemGeom<CDV>::BAND);                                   \
+        const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));                                               \
+        hipLaunchKernelGGL((stem_kernel<TT, CDV>), grid, dim3(512), 0, st, (const TT*)xp, (const TT*)packed, bias, \
+                           (TT*)out, n_img, relu);                                                              \
+    }
+    if (dtype == CP360_BF16) { if (cube_dim == 224) CP360_STEM(bf16_raw, 224) else CP360_STEM(bf16_raw, 512) }
+    else if (dtype == CP360_F16) { if (cube_dim == 224) CP360_STEM(f16_raw, 224) else CP360_STEM(f16_raw, 512) }
+#undef CP360_STEM
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

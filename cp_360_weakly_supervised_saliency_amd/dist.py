@@ -17,6 +17,10 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher (torchrun).
     Returns (rank, world_size, local_rank).  Single-process when WORLD_SIZE is unset."""
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer registration fails with
+    # hipIpcGetMemHandle: invalid argument (it is exported on the boxes already; harmless to repeat, and it must be
+    # set before the first HIP call of the process)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))

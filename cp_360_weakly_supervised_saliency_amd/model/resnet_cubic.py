@@ -215,7 +215,7 @@ class ResNet(nn.Module):
         Bottleneck (conv2 -> conv3 + residual / downsample -> the next block's conv1, csrc/l1block.hip)."""
         dt = _DTYPES[self.precision]
         blks = list(self.layer1)
-        if not (FUSE_LAYER1 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == 56 and x.shape[2] == 56
+        if not (FUSE_LAYER1 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] and x.shape[1] in (56, 128)
                 and blks[0].stride == 1 and blks[0].downsample is not None
                 and all(b.downsample is None for b in blks[1:])):
             for blk in blks:
@@ -235,7 +235,7 @@ class ResNet(nn.Module):
         dt = _DTYPES[self.precision]
         blks = list(self.layer2)
         x = blks[0].forward_nhwc(x)
-        if not (FUSE_LAYER2 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == 28 and x.shape[2] == 28
+        if not (FUSE_LAYER2 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] and x.shape[1] in (28, 64)
                 and all(b.downsample is None and b.stride == 1 for b in blks[1:])):
             for blk in blks[1:]:
                 x = blk.forward_nhwc(x)

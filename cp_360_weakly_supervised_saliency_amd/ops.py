@@ -299,10 +299,10 @@ class Conv:
             t = torch.empty(L.cp360_stem_packed_bytes(code), dtype=torch.uint8, device=self.device)
             check(L.cp360_stem_pack_weights(code, ptr(w), ptr(self._scale), ptr(t), stream()))
             self._stem_packed = t
-        n_img = xp.shape[0]
-        out = torch.empty((n_img, 112, 112, 64), dtype=self.dtype, device=xp.device)
+        n_img, cd = xp.shape[0], xp.shape[1] - 6
+        out = torch.empty((n_img, cd // 2, cd // 2, 64), dtype=self.dtype, device=xp.device)
         check(L.cp360_stem_forward(code, ptr(xp.contiguous()), ptr(self._stem_packed), ptr(self.bias), ptr(out), n_img,
-                                   224, int(self.relu), stream()))
+                                   cd, int(self.relu), stream()))
         return out
 
     def _band_resident(self, x):
@@ -333,7 +333,7 @@ class Conv:
         n_img, h_in, w_in, cx = x.shape
         if (x2 is not None) != (self.second is not None):
             raise ValueError("x2 goes with a conv built with second=...")
-        if (self.stem and h_in == 230 and w_in == 230 and cx == 4 and residual is None and out is None and not raw_f32
+        if (self.stem and h_in == w_in and h_in in (230, 518) and cx == 4 and residual is None and out is None and not raw_f32
                 and splits is None and tile_px == 0 and self.dtype in (torch.bfloat16, torch.float16)
                 and x.dtype == self.dtype):
             return self._stem_resident(x)
@@ -445,8 +445,8 @@ class L1Block:
         w2, s2, b2 = conv2
         if tuple(w2.shape) != (64, 64, 3, 3) or tuple(conv3[0].shape[:2]) != (256, 64):
             raise ValueError("L1Block is layer1's geometry: conv2 64->64 3x3, conv3 64->256 1x1")
-        self.w2 = torch.empty(L.cp360_band3x3_packed_bytes(code), dtype=torch.uint8, device=self.device)
-        check(L.cp360_band3x3_pack_weights(code, ptr(f32(w2)), ptr(f32(s2)), ptr(self.w2), stream()))
+        self.w2 = torch.empty(L.cp360_l1block_conv2_bytes(code), dtype=torch.uint8, device=self.device)
+        check(L.cp360_l1block_pack_conv2(code, ptr(f32(w2)), ptr(f32(s2)), ptr(self.w2), stream()))
         self.b2 = f32(b2)
         w3, s3, b3 = conv3
         self.w3 = frag_pack_1x1(w3, s3, dtype, 0, self.device)
@@ -467,23 +467,26 @@ class L1Block:
             self.b1 = f32(b1)
 
     def __call__(self, mid, residual=None, x_ds=None):
-        """mid [n_img, 56, 56, 64]; residual [n_img, 56, 56, 256] (identity blocks) or x_ds [n_img, 56, 56, 64]
-        (the first block).  Returns (out [n_img, 56, 56, 256], next conv1's output [n_img, 56, 56, 64] or None)."""
+        """mid [n_img, n, n, 64] with n = 56 (cube 224) or 128 (cube 512); residual [n_img, n, n, 256] (identity blocks)
+        or x_ds [n_img, n, n, 64] (the first block).  Returns (out [n_img, n, n, 256], next conv1's output
+        [n_img, n, n, 64] or None)."""
         require_gpu(mid, residual, x_ds)
         if (self.wd is None) != (x_ds is None) or (residual is None) == (x_ds is None):
             raise ValueError("identity blocks take residual=, the downsample block takes x_ds=")
-        n_img = mid.shape[0]
-        _check_buf('mid', mid, self.dtype, (n_img, 56, 56, 64))
-        _check_buf('residual', residual, self.dtype, (n_img, 56, 56, 256))
-        _check_buf('x_ds', x_ds, self.dtype, (n_img, 56, 56, 64))
+        n_img, n = mid.shape[0], mid.shape[1]
+        if n not in (56, 128):
+            raise ValueError("L1Block handles 56x56 and 128x128 faces")
+        _check_buf('mid', mid, self.dtype, (n_img, n, n, 64))
+        _check_buf('residual', residual, self.dtype, (n_img, n, n, 256))
+        _check_buf('x_ds', x_ds, self.dtype, (n_img, n, n, 64))
         for t in (mid, residual, x_ds):
             if t is not None and t.shape[3] not in (64, 256):
                 raise ValueError("dense NHWC tensors only")
-        out = torch.empty((n_img, 56, 56, 256), dtype=self.dtype, device=mid.device)
-        nxt = None if self.w1 is None else torch.empty((n_img, 56, 56, 64), dtype=self.dtype, device=mid.device)
+        out = torch.empty((n_img, n, n, 256), dtype=self.dtype, device=mid.device)
+        nxt = None if self.w1 is None else torch.empty((n_img, n, n, 64), dtype=self.dtype, device=mid.device)
         check(lib().cp360_l1block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
                                           ptr(self.b3), ptr(residual), ptr(x_ds), ptr(self.wd), ptr(out), ptr(self.w1),
-                                          ptr(self.b1), ptr(nxt), n_img, 56, stream()))
+                                          ptr(self.b1), ptr(nxt), n_img, n, stream()))
         return out, nxt
 
 
@@ -508,16 +511,18 @@ class L2Block:
         self.b3 = f32(b3)
 
     def __call__(self, mid, residual):
-        """mid [n_img, 28, 28, 128], residual [n_img, 28, 28, 512] -> out [n_img, 28, 28, 512]."""
+        """mid [n_img, n, n, 128], residual [n_img, n, n, 512] -> out [n_img, n, n, 512]; n = 28 (cube 224) or 64 (cube 512)."""
         require_gpu(mid, residual)
-        n_img = mid.shape[0]
-        _check_buf('mid', mid, self.dtype, (n_img, 28, 28, 128))
-        _check_buf('residual', residual, self.dtype, (n_img, 28, 28, 512))
+        n_img, n = mid.shape[0], mid.shape[1]
+        if n not in (28, 64):
+            raise ValueError("L2Block handles 28x28 and 64x64 faces")
+        _check_buf('mid', mid, self.dtype, (n_img, n, n, 128))
+        _check_buf('residual', residual, self.dtype, (n_img, n, n, 512))
         if mid.shape[3] != 128 or residual.shape[3] != 512:
             raise ValueError("dense NHWC tensors only")
-        out = torch.empty((n_img, 28, 28, 512), dtype=self.dtype, device=mid.device)
+        out = torch.empty((n_img, n, n, 512), dtype=self.dtype, device=mid.device)
         check(lib().cp360_l2block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
-                                          ptr(self.b3), ptr(residual), ptr(out), n_img, 28, stream()))
+                                          ptr(self.b3), ptr(residual), ptr(out), n_img, n, stream()))
         return out
 
 

@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 206
+#define CP360_VERSION 207
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -237,7 +237,7 @@ int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const floa
 /* ------------------------------------------------------------------ K3a: resident-patch stem
  * conv 7x7 stride 2 (3 -> 64) + folded BatchNorm + ReLU of model/resnet_cubic.py:115-128,163-168 on the
  * materialised CubePad(3) input [n_img, cd+6, cd+6, 4] (NHWC4, 16-bit) -> [n_img, cd/2, cd/2, 64], for
- * cube_dim 224 and CP360_BF16 / CP360_F16 (other sizes / f32: CP360_ERR_UNSUPPORTED - use the generic
+ * cube_dim 224 or 512 and CP360_BF16 / CP360_F16 (other sizes / f32: CP360_ERR_UNSUPPORTED - use the generic
  * convolution in its "7 taps of 8 pixels x 4 channels" form).  Same arithmetic as the generic path
  * (16-bit products, f32 accumulate, one rounding); the input rows a band of output rows needs are
  * copied to LDS once and the MFMA fragments are read from the raw rows (no im2col anywhere).
@@ -265,10 +265,11 @@ int cp360_band3x3_forward(int dtype, const void* x, const void* packed, const fl
  * One kernel for  conv2 (CubePad(1) + 3x3, 64 -> 64) + bn2 + relu  ->  conv3 (1x1, 64 -> 256) + bn3
  * + (identity residual | downsample(x) = conv1x1 64 -> 256 + bn) + relu  ->  [optional] the NEXT block's
  * conv1 (1x1, 256 -> 64) + bn1 + relu : model/resnet_cubic.py:85-106 for the three Bottlenecks of layer1 at
- * cube size 224 (56x56 faces), CP360_BF16 / CP360_F16 only.  Nothing between the convolutions goes through
+ * cube size 224 (56x56 faces) or 512 (128x128 faces: `face`), CP360_BF16 / CP360_F16 only.  Nothing between the
+ * convolutions goes through
  * HBM: conv2's accumulators feed conv3 from registers, conv3's rounded output feeds the next conv1.
- *   mid        [n_img, 56, 56, 64]   this block's conv1 output (NHWC)
- *   w2_packed  cp360_band3x3_pack_weights layout, bias2 f32 [64]
+ *   mid        [n_img, face, face, 64]   this block's conv1 output (NHWC); the other tensors likewise
+ *   w2_packed  cp360_l1block_pack_conv2(w2 [64, 64, 3, 3]) (fragment order, cp360_l1block_conv2_bytes), bias2 f32 [64]
  *   w3_frags   cp360_frag_pack_1x1(w3 [256, 64], order 0), bias3 f32 [256] (with the downsample branch: b3 + bd)
  *   residual   [n_img, 56, 56, 256] or NULL;  x_ds [n_img, 56, 56, 64] + wd_frags (order 0, [256, 64]) or NULL:
  *              exactly one of residual / x_ds
@@ -280,6 +281,8 @@ int cp360_band3x3_forward(int dtype, const void* x, const void* packed, const fl
 /* MFMA A-fragment packing of a 1x1 filter w [n_out, k] (f32, times scale[n_out] or NULL): 1 KiB fragments of
  * 16 rows x 32 k, rows in the kernels' acc_chan order; order 0 = row-block major ([n_out/16][k/32]),
  * order 1 = k-block major ([k/32][n_out/16]).  n_out % 32 == 0, k % 32 == 0. */
+size_t cp360_l1block_conv2_bytes(int dtype);
+int cp360_l1block_pack_conv2(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream);
 size_t cp360_frag_packed_bytes(int dtype, int n_out, int k);
 int cp360_frag_pack_1x1(int dtype, const float* w, const float* scale, void* packed, int n_out, int k,
                         int order, void* stream);
@@ -290,8 +293,8 @@ int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, con
 
 /* ------------------------------------------------------------------ K3e: fused Bottleneck tail (layer2)
  * conv2 (CubePad(1) + 3x3, 128 -> 128) + bn2 + relu -> conv3 (1x1, 128 -> 512) + bn3 + identity residual + relu
- * of layer2's identity Bottlenecks (model/resnet_cubic.py:85-106) at cube size 224 (28x28 faces), CP360_BF16 /
- * CP360_F16, in one kernel (csrc/l2block.hip).
+ * of layer2's identity Bottlenecks (model/resnet_cubic.py:85-106) at cube size 224 (28x28 faces) or 512 (64x64:
+ * `face`), CP360_BF16 / CP360_F16, in one kernel (csrc/l2block.hip).
  *   mid [n_img, 28, 28, 128], w2_packed = cp360_l2block_pack_weights(w2 [128,128,3,3]), bias2 f32 [128],
  *   w3_frags = cp360_frag_pack_1x1(w3 [512, 128], order 0), bias3 f32 [512],
  *   residual / out [n_img, 28, 28, 512].  Other face sizes: CP360_ERR_UNSUPPORTED. */

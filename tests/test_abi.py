@@ -92,7 +92,7 @@ def test_stem_and_resize_entry_points_validate_without_gpu():
     assert L.cp360_stem_packed_bytes(_lib.BF16) == 7 * 64 * 64 and L.cp360_stem_packed_bytes(_lib.F32) == 0
     one = C.c_void_p(16)
     assert L.cp360_stem_forward(_lib.BF16, None, one, None, one, 6, 224, 1, None) == -5          # NULL
-    assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 6, 512, 1, None) == -8           # other cube sizes
+    assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 6, 256, 1, None) == -8           # cube sizes other than 224 / 512
     assert L.cp360_stem_forward(_lib.BF16, one, one, None, one, 0, 224, 1, None) == -1           # bad shape
     assert L.cp360_band3x3_packed_bytes(_lib.F16) == 9 * 64 * 128
     assert L.cp360_band3x3_forward(_lib.BF16, one, one, None, one, 6, 28, 128, 1, None) == -8     # other shapes

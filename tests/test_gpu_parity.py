@@ -268,6 +268,23 @@ def test_resnet_fused_downsample_equals_separate(golden_dir):
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_layer1_fused_block_kernel_cube512_faces(prec):
+    """K3d at 128x128 faces (cube 512, BASELINE config C5): two output rows per workgroup, two waves per row."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4700, (6, 128, 128, 64), 0.0, 1.0))).to(DEV).to(dt)
+    got = m.layer1_nhwc(x).float().cpu().numpy()
+    rc.FUSE_LAYER1 = False
+    try:
+        sep = m.layer1_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_LAYER1 = True
+    assert got.shape == (6, 128, 128, 256)
+    assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 @pytest.mark.parametrize('n_img', [6, 12])
 def test_layer1_fused_block_kernel(prec, n_img):
     """K3d (csrc/l1block.hip): layer1 as conv1 + one launch per Bottleneck vs (a) the per-convolution path and
@@ -294,6 +311,23 @@ def test_layer1_fused_block_kernel(prec, n_img):
             xc = o_resnet._bottleneck(xc, sdt, 'layer1.%d' % b, 1, b == 0)
         want = xc.permute(0, 2, 3, 1).numpy()
     assert rel_err(got, want) <= 4 * _TOL[prec], rel_err(got, want)
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_layer2_fused_tail_kernel_cube512_faces(prec):
+    """K3e at 64x64 faces (cube 512, BASELINE config C5): bands of two output rows (128 pixels = 8 pixel blocks)."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4800, (6, 128, 128, 256), 0.0, 1.0))).to(DEV).to(dt)
+    got = m.layer2_nhwc(x).float().cpu().numpy()
+    rc.FUSE_LAYER2 = False
+    try:
+        sep = m.layer2_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_LAYER2 = True
+    assert got.shape == (6, 64, 64, 512)
+    assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
@@ -437,8 +471,8 @@ def test_stem_resident_patch_kernel_cube224(prec):
     168 tiles on <= 256 workgroups... so also run 60 faces to make workgroups loop) against torch-CPU on the
     same rounded operands, and against the generic implicit GEMM (summation order only)."""
     dt = _TDT[prec]
-    for n_img, seed in ((12, 9600), (60, 9610)):
-        x = hashrng.normal(seed, (n_img, 3, 224, 224))
+    for n_img, seed, cd in ((12, 9600, 224), (60, 9610, 224), (6, 9620, 512), (18, 9630, 512)):   # 512: BASELINE config C5
+        x = hashrng.normal(seed, (n_img, 3, cd, cd))
         w = hashrng.normal(9601, (64, 3, 7, 7), 0, (2.0 / (49 * 64)) ** 0.5)
         scale = hashrng.uniform(9602, (64,), 0.5, 1.5)
         bias = hashrng.normal(9603, (64,), 0, 0.1)
@@ -446,13 +480,13 @@ def test_stem_resident_patch_kernel_cube224(prec):
         x3 = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV))
         x4 = ops.cubepad_nhwc(x3, 0, c_out=4)
         x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)
-        xp = ops.cubepad_nhwc(x4, 3)                                   # [n_img, 230, 230, 4]
+        xp = ops.cubepad_nhwc(x4, 3)                                   # [n_img, cd + 6, cd + 6, 4]
         got = conv(xp)                                                 # resident-patch kernel
-        assert got.shape == (n_img, 112, 112, 64)
+        assert got.shape == (n_img, cd // 2, cd // 2, 64)
         gen = conv(xp, tile_px=0, splits=1)                            # splits given -> generic path
         g, e = got.float().cpu().numpy(), gen.float().cpu().numpy()
         assert rel_err(g, e) <= _TOL[prec], rel_err(g, e)
-        if n_img == 12:
+        if n_img in (12, 6):
             rb = lambda a: torch.from_numpy(a).to(dt).float().numpy()
             w_ref = rb(w * scale[:, None, None, None])
             want = _conv_ref(rb(x), w_ref, None, bias, 2, 3, True)
