@@ -10,6 +10,7 @@
 // integer work, bit-exact by construction (tests compare with PIL itself).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define CP360_RESIZE_PRECISION_BITS (32 - 8 - 2)
 
@@ -121,6 +122,98 @@ __global__ __launch_bounds__(256) void resize_pass_kernel(const uint8_t* __restr
     }
 }
 
+// ---- faster passes for the common shapes (row bytes a multiple of 4; windows of at most 1024 input pixels per 256
+// outputs).  The kernel above issues 3 byte loads per tap and pixel: 0.10 of the HBM peak (profiles/r02_hbm_kernels.md).
+// Vertical: a row is W*3 independent bytes with the same coefficients, so a thread owns FOUR consecutive bytes (one
+// dword load per tap, coalesced across the row).  Horizontal: a workgroup stages the input window of 256 output pixels
+// in LDS with dword loads and the taps read bytes from there.  Both: XCD-contiguous work ranges (neighbouring output rows
+// share input rows).  Same integer arithmetic, bit-exact.
+__global__ __launch_bounds__(256) void resize_v4_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                        int ksize, int F, int h_in, int row_dwords, int h_out) {
+    const long long total = (long long)F * h_out * row_dwords;
+    const long long chunk = (total + 7) / 8;
+    const long long lo_w = (blockIdx.x & 7) * chunk, hi_w = min(total, lo_w + chunk);
+    const long long stride = (long long)(gridDim.x >> 3) * 256;
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(out);
+    for (long long idx = lo_w + (long long)(blockIdx.x >> 3) * 256 + threadIdx.x; idx < hi_w; idx += stride) {
+        const int xd = (int)(idx % row_dwords);
+        const long long t = idx / row_dwords;
+        const int y = (int)(t % h_out), f = (int)(t / h_out);
+        const int lo = bounds[2 * y], n = bounds[2 * y + 1];
+        const int* k = kk + (size_t)y * ksize;
+        const uint32_t* src = in32 + ((size_t)f * h_in + lo) * row_dwords + xd;
+        int s0 = 1 << (CP360_RESIZE_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+        for (int i = 0; i < n; ++i) {
+            const int c = k[i];
+            const uint32_t v = src[(size_t)i * row_dwords];
+            s0 += c * (int)(v & 0xff);
+            s1 += c * (int)((v >> 8) & 0xff);
+            s2 += c * (int)((v >> 16) & 0xff);
+            s3 += c * (int)(v >> 24);
+        }
+        out32[idx] = (uint32_t)clip8(s0) | ((uint32_t)clip8(s1) << 8) | ((uint32_t)clip8(s2) << 16) | ((uint32_t)clip8(s3) << 24);
+    }
+}
+
+constexpr int RH_MAX_PX = 1024;          // input pixels a workgroup's window may span
+__global__ __launch_bounds__(256) void resize_h_lds_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                           int ksize, int rows, int w_in, int w_out, int xblocks,
+                                                           size_t in_bytes) {
+    __shared__ uint32_t win[(RH_MAX_PX * 3 + 8) / 4 + 1];
+    // XCD-contiguous ranges of (row, x block) items
+    const int items = rows * xblocks;
+    const int chunk = (items + 7) / 8;
+    const int lo_i = (blockIdx.x & 7) * chunk, hi_i = min(items, lo_i + chunk);
+    for (int item = lo_i + (int)(blockIdx.x >> 3); item < hi_i; item += (int)(gridDim.x >> 3)) {
+        const int row = item / xblocks, xb = item - row * xblocks;
+        const int x_first = xb * 256, x_last = min(w_out - 1, x_first + 255);
+        const int lo0 = bounds[2 * x_first];
+        const int hi0 = bounds[2 * x_last] + bounds[2 * x_last + 1];
+        const size_t b0 = ((size_t)row * w_in + lo0) * 3, b1 = ((size_t)row * w_in + hi0) * 3;
+        const size_t a0 = b0 & ~(size_t)3;                         // dword-aligned start (the tensor base is 4-byte aligned)
+        const int ndw = (int)((b1 - a0 + 3) >> 2);
+        __syncthreads();                                           // the previous item's readers are done
+        for (int i = threadIdx.x; i < ndw; i += 256) {
+            const size_t a = a0 + 4 * (size_t)i;
+            uint32_t v;
+            if (a + 4 <= in_bytes) v = *reinterpret_cast<const uint32_t*>(in + a);
+            else {
+                v = 0;
+                for (int e = 0; e < 4 && a + e < in_bytes; ++e) v |= (uint32_t)in[a + e] << (8 * e);
+            }
+            win[i] = v;
+        }
+        __syncthreads();
+        const int x = x_first + threadIdx.x;
+        if (x <= x_last) {
+            const int lo = bounds[2 * x], n = bounds[2 * x + 1];
+            const int* k = kk + (size_t)x * ksize;
+            const uint8_t* w8 = reinterpret_cast<const uint8_t*>(win) + (b0 - a0) + (size_t)(lo - lo0) * 3;
+            int s0 = 1 << (CP360_RESIZE_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+            for (int i = 0; i < n; ++i) {
+                const int c = k[i];
+                s0 += c * w8[3 * i];
+                s1 += c * w8[3 * i + 1];
+                s2 += c * w8[3 * i + 2];
+            }
+            uint8_t* dst = out + ((size_t)row * w_out + x) * 3;
+            dst[0] = clip8(s0);
+            dst[1] = clip8(s1);
+            dst[2] = clip8(s2);
+        }
+    }
+}
+
+// host check for the LDS kernel: the widest input window of any 256-output block (the tables are device memory, so the
+// bound comes from the geometry: support * scale on both sides + 256 * scale)
+static bool h_window_fits(int w_in, int w_out, int ksize) {
+    const double scale = (double)w_in / w_out;
+    return 256.0 * scale + ksize + 2 <= RH_MAX_PX;
+}
+
 extern "C" int cp360_resize_lanczos_u8(const void* in, void* out, void* tmp, int F, int h_in, int w_in, int h_out,
                                        int w_out, const int* hbounds, const int* hkk, int hksize, const int* vbounds,
                                        const int* vkk, int vksize, void* stream) {
@@ -141,15 +234,34 @@ extern "C" int cp360_resize_lanczos_u8(const void* in, void* out, void* tmp, int
         return CP360_OK;
     }
     const uint8_t* cur = (const uint8_t*)in;
+    static const int slow = []() { const char* e = getenv("CP360_RESIZE_BYTEWISE"); return e ? atoi(e) : 0; }();   // A/B switch
     if (need_h) {       // [F, h_in, w_in] -> [F, h_in, w_out]
         uint8_t* dst = need_v ? (uint8_t*)tmp : (uint8_t*)out;
-        hipLaunchKernelGGL((resize_pass_kernel<true>), dim3(blocks_of((long long)F * h_in * w_out)), dim3(256), 0, st, cur,
-                           dst, hbounds, hkk, hksize, F, h_in, w_in, h_in, w_out);
+        if (!slow && h_window_fits(w_in, w_out, hksize) && (long long)F * h_in < (1 << 24)) {
+            const int xblocks = (w_out + 255) / 256;
+            long long items = (long long)F * h_in * xblocks;
+            unsigned blocks = (unsigned)(items > 256 * 16 ? 256 * 16 : (items + 7) / 8 * 8);
+            hipLaunchKernelGGL(resize_h_lds_kernel, dim3(blocks), dim3(256), 0, st, cur, dst, hbounds, hkk, hksize, F * h_in,
+                               w_in, w_out, xblocks, (size_t)F * h_in * w_in * 3);
+        } else {
+            hipLaunchKernelGGL((resize_pass_kernel<true>), dim3(blocks_of((long long)F * h_in * w_out)), dim3(256), 0, st,
+                               cur, dst, hbounds, hkk, hksize, F, h_in, w_in, h_in, w_out);
+        }
         cur = dst;
     }
-    if (need_v)         // [F, h_in, w_out] -> [F, h_out, w_out]
-        hipLaunchKernelGGL((resize_pass_kernel<false>), dim3(blocks_of((long long)F * h_out * w_out)), dim3(256), 0, st,
-                           cur, (uint8_t*)out, vbounds, vkk, vksize, F, h_in, w_out, h_out, w_out);
+    if (need_v) {       // [F, h_in, w_out] -> [F, h_out, w_out]
+        if (!slow && (w_out * 3) % 4 == 0 && (reinterpret_cast<size_t>(cur) & 3) == 0 && (reinterpret_cast<size_t>(out) & 3) == 0) {
+            const long long total = (long long)F * h_out * (w_out * 3 / 4);
+            long long b = (total + 255) / 256;
+            if (b > 256 * 32) b = 256 * 32;
+            b = (b + 7) / 8 * 8;
+            hipLaunchKernelGGL(resize_v4_kernel, dim3((unsigned)b), dim3(256), 0, st, cur, (uint8_t*)out, vbounds, vkk, vksize,
+                               F, h_in, w_out * 3 / 4, h_out);
+        } else {
+            hipLaunchKernelGGL((resize_pass_kernel<false>), dim3(blocks_of((long long)F * h_out * w_out)), dim3(256), 0, st,
+                               cur, (uint8_t*)out, vbounds, vkk, vksize, F, h_in, w_out, h_out, w_out);
+        }
+    }
     CP360_CHECK_HIP();
     return CP360_OK;
 }
