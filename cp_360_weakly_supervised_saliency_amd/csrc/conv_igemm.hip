@@ -1280,6 +1280,16 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
             const unsigned w = j < 2 ? e03.x : j < 4 ? e03.y : j < 6 ? e03.z : j < 8 ? e03.w : e4;
             return ((j & 1) ? (w >> 16) : (w & 0xffffu)) ^ cx;
         };
+        // byte addresses (inside lds) of the NEXT head's B fragments, decoded from the entries at the end of a TAIL -
+        // under its MFMAs and before a barrier - so that a HEAD opens with its ds_reads instead of ~40 VALU
+        // instructions in the window right behind the barrier (ablation: the kernel without the per-sub-step entry
+        // handling ran 8 % faster; MI355X_MICROARCH.md, two waves per SIMD, item 6)
+        unsigned ba[MJ];
+        auto decode = [&]() __attribute__((always_inline)) {
+            const unsigned abase = (unsigned)(G::OFF_ACT + abuf * G::ATILE);
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) ba[j] = abase + ent(j);
+        };
         // prologue: the first activation tile - and the second one when the range starts inside a
         // channel block, because the tap-0 request of the next block would come too late - (older than
         // every weight DMA), then NW-1 weight stages
@@ -1293,13 +1303,14 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
                 if (nloc > k) { woff += WSTEP; issue_w(0, sb + k * G::WSTAGE); issue_w(1, sb + k * G::WSTAGE); }
         }
         load_ent(tap);
+        decode();
         int stage = 0;
-        u32x4 a[4], b[JH];
+        u32x4 a[4], b[MJ];
         if (LAG) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int j = 0; j < JH; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
+            for (int j = 0; j < MJ; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
         }
         // HEAD / TAIL / stagger: see ring_body.  New here: B fragments come from the resident
         // activation tile through the entries; at tap 0 the tile of the NEXT channel block is
@@ -1307,23 +1318,19 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
 #define CP360_CLIP_HEAD(REFILL)                                                                            \
         {                                                                                                  \
             const unsigned char* As = lds + stage * G::WSTAGE;                                             \
-            const unsigned char* Ab = lds + G::OFF_ACT + abuf * G::ATILE;                                  \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
                 a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \
-            _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                 \
-                b[j] = *reinterpret_cast<const u32x4*>(Ab + ent(j));                                       \
+            _Pragma("unroll") for (int j = 0; j < MJ; ++j)   /* every column's fragment: all reads of the sub-step up front */ \
+                b[j] = *reinterpret_cast<const u32x4*>(lds + ba[j]);                                       \
             unsigned sbase = 0;                                                                            \
             if (REFILL) {                                                                                  \
                 woff += WSTEP;                                                                             \
                 sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)(stage == 0 ? G::NW - 1 : stage - 1) * G::WSTAGE); \
             }                                                                                              \
-            const bool trig = tap == 0;                                                                    \
-            _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                               \
-                if (j == 0 && trig) issue_act_tile();                                                      \
-                if (REFILL && j < 2) issue_w(j, sbase);                                                    \
+            if (tap == 0) issue_act_tile();                                                                \
+            if (REFILL) { issue_w(0, sbase); issue_w(1, sbase); }                                          \
+            _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                 \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);         \
-                if (JH + j < MJ) b[j] = *reinterpret_cast<const u32x4*>(Ab + ent(JH + j));                 \
-            }                                                                                              \
             stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \
             ++tap;                                                                                         \
             if (tap == TAPS) {                                                                             \
@@ -1335,7 +1342,8 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
 #define CP360_CLIP_TAIL()                                                                                  \
         {                                                                                                  \
             _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                                \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j - JH]);    \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);         \
+            decode();                                                                                      \
         }
 #define CP360_CLIP_STEP(REFILL)                                                                            \
         {                                                                                                  \
@@ -1416,6 +1424,7 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     }
 }
 
+constexpr int CLIP_JH = 0;
 template <typename T, bool FACE>
 __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
     typedef ClipGeom<FACE> G;
@@ -1455,12 +1464,13 @@ __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
         }
         __syncthreads();
     }
+    constexpr int JHC = CLIP_JH;                       // MFMA columns issued in the load half of a sub-step (see clip_body)
     if constexpr (FACE) {
-        if (wave < 4) clip_body<T, 8, 4, false, true>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
-        else          clip_body<T, 8, 4, true, true>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+        if (wave < 4) clip_body<T, 8, JHC, false, true>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 8, JHC, true, true>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
     } else {
-        if (wave < 4) clip_body<T, 10, 5, false, false>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
-        else          clip_body<T, 9, 5, true, false>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+        if (wave < 4) clip_body<T, 10, JHC, false, false>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 9, JHC, true, false>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
     }
 }
 

@@ -60,6 +60,47 @@ for v in variants:
             '        if (acc[0][0][0] == 1.2345e-30f) p.out[0] = 1;\n        return;')
     if v == 'ring_nok':        # ring kernel: skip the K loop (epilogue only)
         sub('    const int nloc = s_end - s_begin;\n    const int sub_per_tap = 2 * p.steps_per_tap;', '    const int nloc = 0 * (s_end - s_begin);\n    const int sub_per_tap = 2 * p.steps_per_tap;')
+    if v == 'clip_nobar2':     # clip kernel: drop the second barrier of a sub-step (racy: timing only)
+        sub("            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            __builtin_amdgcn_s_barrier();                                                                  \\\n",
+            "            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n")
+    if v == 'clip_notab':      # clip kernel: no per-tap table loads (entries of tap 0 throughout)
+        sub('            load_ent(tap);                                                                                 \\\n        }', '        }')
+    if v == 'clip_decode_head':   # clip kernel: decode the B addresses at the START of a HEAD (the round-1 placement) instead of in the TAIL
+        sub("            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n            _Pragma(\"unroll\") for (int i = 0; i < 4; ++i)                                                  \\\n                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \\\n            _Pragma(\"unroll\") for (int j = 0; j < JH; ++j)                                                 \\\n                b[j] = *reinterpret_cast<const u32x4*>(lds + ba[j]);",
+            "            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n            decode();                                                                                      \\\n            _Pragma(\"unroll\") for (int i = 0; i < 4; ++i)                                                  \\\n                a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \\\n            _Pragma(\"unroll\") for (int j = 0; j < JH; ++j)                                                 \\\n                b[j] = *reinterpret_cast<const u32x4*>(lds + ba[j]);")
+        sub("            decode();                                                                                      \\\n        }", "        }")
+    if v == 'clip_stamps':     # clip kernel: s_memtime stamps around the two halves and the two barriers of a sub-step
+        sub('__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};',
+            '__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};\n'
+            '__device__ unsigned long long g_stamp[8][8];\n'
+            'extern "C" int cp360_debug_stamps(unsigned long long* out_host, int reset) {\n'
+            '    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) != hipSuccess) return -7;\n'
+            '    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess) return -7; }\n'
+            '    return 0;\n}\n'
+            '#define CP360_STAMP(K) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; '
+            'asm volatile("s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); '
+            'st_acc[K] += (unsigned)(t_ - st_prev); st_prev = t_; }')
+        sub("            if (LAG) asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");                                    \\\n            __builtin_amdgcn_s_barrier();                                                                  \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            __builtin_amdgcn_s_barrier();                                                                  \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            if (!LAG) CP360_CLIP_TAIL() else CP360_CLIP_HEAD(REFILL)                                       \\\n",
+            "            CP360_STAMP(0)                                                                                 \\\n            if (LAG) asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");                                    \\\n            __builtin_amdgcn_s_barrier();                                                                  \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            CP360_STAMP(1)                                                                                 \\\n            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            CP360_STAMP(2)                                                                                 \\\n            __builtin_amdgcn_s_barrier();                                                                  \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            CP360_STAMP(3)                                                                                 \\\n            if (!LAG) CP360_CLIP_TAIL() else CP360_CLIP_HEAD(REFILL)                                       \\\n            CP360_STAMP(4)                                                                                 \\\n")
+        sub("        constexpr int YW = 2 * (G::NW - 2);\n        const int na = xw ? 3 : 2;\n        int it = 0;",
+            "        constexpr int YW = 2 * (G::NW - 2);\n        const int na = xw ? 3 : 2;\n        int it = 0;\n"
+            "        unsigned st_acc[5] = {0u, 0u, 0u, 0u, 0u};\n        unsigned long long st_prev;\n"
+            "        asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(st_prev) :: \"memory\");")
+        sub("        if (LAG) CP360_CLIP_TAIL()\n#undef CP360_CLIP_STEP",
+            "        if (LAG) CP360_CLIP_TAIL()\n        if (lane == 0) {\n            for (int k = 0; k < 5; ++k) atomicAdd(&g_stamp[wave][k], (unsigned long long)st_acc[k]);\n"
+            "            atomicAdd(&g_stamp[wave][7], (unsigned long long)nloc);\n        }\n#undef CP360_CLIP_STEP")
+    if v == 'clip_headprio':   # clip kernel: the wave in its HEAD (LDS-fed half) gets matrix-pipe priority over its SIMD partner's TAIL
+        sub("            const bool trig = tap == 0;                                                                    \\\n",
+            "            const bool trig = tap == 0;                                                                    \\\n            __builtin_amdgcn_s_setprio(1);                                                                 \\\n")
+        sub("            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;",
+            "            __builtin_amdgcn_s_setprio(0);                                                                 \\\n            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;")
+    if v == 'clip_lagprio':    # only the lagging waves raise their priority during HEAD
+        sub("            const bool trig = tap == 0;                                                                    \\\n",
+            "            const bool trig = tap == 0;                                                                    \\\n            if (LAG) __builtin_amdgcn_s_setprio(1);                                                        \\\n")
+        sub("            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;",
+            "            if (LAG) __builtin_amdgcn_s_setprio(0);                                                        \\\n            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;")
+    if v.startswith('clip_jh'):   # clip kernel: MFMA columns issued in the load half (0 = pure load / compute halves)
+        sub('constexpr int CLIP_JH = 0;', 'constexpr int CLIP_JH = %d;' % int(v[7:]))
     if v == 'clip_nw7':        # clip kernel: seven weight stages
         sub('static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 7, NA = 2;')
     if v == 'clip_nw5':
