@@ -975,12 +975,17 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
         // registers.  Stage s is read between B1(s) and B1(s+1) by both groups and refilled (with
         // sub-step s+4) after B1(s+1), exactly as without the stagger; a lagging wave drains its
         // LDS reads (lgkmcnt) before B1 because the tail operands it read last are first used after it.
-        u32x4 a[4], b[JH];
+        // ALLUP (the 8-wave big-tile variants): the load half issues every fragment read and the refill DMA and no
+        // MFMA, the compute half all of them from registers (as the clip kernel; -8 % there); the short-K two-workgroup
+        // variant (128-VGPR budget) keeps the JH / MJ - JH split with register reuse
+        constexpr bool ALLUP = NS > 2 && MJ <= 8;               // (the 10-block 304-pixel tile would spill: 256 VGPRs)
+        constexpr int NBR = ALLUP ? MJ : JH;
+        u32x4 a[4], b[NBR];
         if (LAG) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int j = 0; j < JH; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
+            for (int j = 0; j < NBR; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
         }
 #define CP360_RING_HEAD(REFILL)                                                                            \
         {                                                                                                  \
@@ -988,28 +993,33 @@ __device__ __forceinline__ void ring_body(const ConvK& p, unsigned char* lds, co
             const unsigned char* Bs = As + BN * 64;                                                        \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                  \
                 a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz64(wch0 + i * 16 + lrow, lchunk));      \
-            _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                 \
+            _Pragma("unroll") for (int j = 0; j < NBR; ++j)                                                \
                 b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + j * 16 + lrow, lchunk));     \
             unsigned sbase = 0;                                                                            \
             if (REFILL) {                                                                                  \
                 advance();                                                                                 \
                 sbase = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)(stage == 0 ? NS - 1 : stage - 1) * STAGE); \
             }                                                                                              \
-            _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                               \
-                if (REFILL && j < D0) issue_one(j, sbase);                                                 \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);         \
-                if (JH + j < MJ)   /* column j is done: its registers take pixel block JH + j */           \
-                    b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + (JH + j) * 16 + lrow, lchunk)); \
+            if (ALLUP) {                                                                                   \
+                _Pragma("unroll") for (int q = 0; q < D0; ++q)                                             \
+                    if (REFILL) issue_one(q, sbase);                                                       \
+            } else {                                                                                       \
+                _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                           \
+                    if (REFILL && j < D0) issue_one(j, sbase);                                             \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);     \
+                    if (JH + j < MJ)   /* column j is done: its registers take pixel block JH + j */       \
+                        b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz64(wrow0 + (JH + j) * 16 + lrow, lchunk)); \
+                }                                                                                          \
+                _Pragma("unroll") for (int q = JH; q < D0; ++q)   /* more DMA passes than MFMA columns (BM = 128) */ \
+                    if (REFILL) issue_one(q, sbase);                                                       \
             }                                                                                              \
-            _Pragma("unroll") for (int q = JH; q < D0; ++q)   /* more DMA passes than MFMA columns (BM = 128) */ \
-                if (REFILL) issue_one(q, sbase);                                                           \
             if (REFILL && G::XWAVES > 0 && xw) issue_one(D0, sbase);                                       \
             stage = stage == NS - 1 ? 0 : stage + 1;                                                       \
         }
 #define CP360_RING_TAIL()                                                                                  \
         {                                                                                                  \
-            _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                                \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j - JH]);    \
+            _Pragma("unroll") for (int j = ALLUP ? 0 : JH; j < MJ; ++j)                                    \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[ALLUP ? j : j - JH]); \
         }
 #define CP360_RING_STEP(REFILL)                                                                            \
         {                                                                                                  \
@@ -1365,10 +1375,10 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
         const int na = xw ? 3 : 2;
         int it = 0;
         for (; it + G::NW - 1 < nloc; ++it) {
-            const bool act_young = tap >= 1 && tap <= G::NW - 2 && it >= tap;
-            if (!act_young) wait_vmcnt<YW>();
-            else if (xw)    wait_vmcnt<YW + 3>();
-            else            wait_vmcnt<YW + 2>();
+            // steady state: always the conservative count.  (When an activation tile is among the younger DMAs the
+            // exact count would be YW + 2 or + 3; the tile was requested up to NW-2 sub-steps ago and has long landed,
+            // and the branch-free loop top measured 1.5-3 % faster.)
+            wait_vmcnt<YW>();
             CP360_CLIP_STEP(true)
         }
         for (; it < nloc; ++it) {                   // drain: no weight refill

@@ -89,14 +89,14 @@ for v in variants:
         sub("        if (LAG) CP360_CLIP_TAIL()\n#undef CP360_CLIP_STEP",
             "        if (LAG) CP360_CLIP_TAIL()\n        if (lane == 0) {\n            for (int k = 0; k < 5; ++k) atomicAdd(&g_stamp[wave][k], (unsigned long long)st_acc[k]);\n"
             "            atomicAdd(&g_stamp[wave][7], (unsigned long long)nloc);\n        }\n#undef CP360_CLIP_STEP")
-    if v == 'clip_headprio':   # clip kernel: the wave in its HEAD (LDS-fed half) gets matrix-pipe priority over its SIMD partner's TAIL
-        sub("            const bool trig = tap == 0;                                                                    \\\n",
-            "            const bool trig = tap == 0;                                                                    \\\n            __builtin_amdgcn_s_setprio(1);                                                                 \\\n")
+    if v == 'clip_loadprio':   # clip kernel: a wave raises its priority for its LOAD half (LDS reads, DMA issue) and drops it for COMPUTE
+        sub("            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n",
+            "            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n            __builtin_amdgcn_s_setprio(2);                                                                 \\\n")
         sub("            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;",
             "            __builtin_amdgcn_s_setprio(0);                                                                 \\\n            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;")
-    if v == 'clip_lagprio':    # only the lagging waves raise their priority during HEAD
-        sub("            const bool trig = tap == 0;                                                                    \\\n",
-            "            const bool trig = tap == 0;                                                                    \\\n            if (LAG) __builtin_amdgcn_s_setprio(1);                                                        \\\n")
+    if v == 'clip_lagloadprio':   # only the lagging (younger) waves raise their priority for their LOAD half
+        sub("            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n",
+            "            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n            if (LAG) __builtin_amdgcn_s_setprio(2);                                                        \\\n")
         sub("            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;",
             "            if (LAG) __builtin_amdgcn_s_setprio(0);                                                        \\\n            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;")
     if v.startswith('clip_jh'):   # clip kernel: MFMA columns issued in the load half (0 = pure load / compute halves)
@@ -106,7 +106,7 @@ for v in variants:
     if v == 'clip_nw5':
         sub('static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 5, NA = 2;')
     if v == 'clip_prio':       # clip kernel: static priority for the lagging half (waves 4-7)
-        sub('    if (wave < 4) clip_body<T, 10, 5, false>', '    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    if (wave < 4) clip_body<T, 10, 5, false>')
+        sub('        if (wave < 4) clip_body<T, 10, JHC, false, false>', '        if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n        if (wave < 4) clip_body<T, 10, JHC, false, false>')
     if v == 'fullline':
         sub('const int drow = 16 * wave + (lane >> 2);', 'const int drow = 16 * wave + (lane >> 3);')
         sub('const int dchunk = (lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3);', 'const int dchunk = lane & 7;')
