@@ -214,6 +214,38 @@ def cpu_baseline(precision, dev, static_precision=None):
             'check': check}
 
 
+def cpu_anchor(reps=5):
+    """BASELINE.md section 4, "sanity anchor": the oracle on all host cores, on the two pieces BASELINE.md section 2
+    timed with the REFERENCE code in the 8-vCPU survey container - CAM() of one cube (6x3x224x224: 0.43 s, min 0.35)
+    and one ConvLSTMCell step (6x1000x7x7: 0.62 s, min 0.54).  Part of the cpu_baseline leg (the only place outside
+    tests/ that runs the oracle); needs no GPU."""
+    from oracle import o_resnet, o_clstm
+    torch.set_num_threads(os.cpu_count() or 1)
+    rs = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.resnet50_state(seed=1).items()}
+    cs = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.clstm_state(seed=2).items()}
+    from cp_360_weakly_supervised_saliency_amd.utils import hashrng
+    cube = hashrng.uniform(41, (6, 3, 224, 224), -1.0, 1.0).astype(np.float32)
+    x = torch.from_numpy(hashrng.uniform(42, (6, 1000, 7, 7), 0.0, 1.0).astype(np.float32))
+    h = torch.zeros_like(x)
+    c = torch.zeros_like(x)
+
+    def med(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return round(float(np.median(ts)), 3), round(float(np.min(ts)), 3)
+    with torch.no_grad():
+        cam = med(lambda: o_resnet.cam_from_cubes(cube, rs))
+        step = med(lambda: o_clstm.clstm_step(x, h, c, cs))
+    return {'cpu_anchor': {'cam_one_cube_s': {'median': cam[0], 'min': cam[1], 'reference_in_survey': [0.43, 0.35]},
+                           'clstm_step_s': {'median': step[0], 'min': step[1], 'reference_in_survey': [0.62, 0.54]},
+                           'threads': torch.get_num_threads(), 'cpu_model': cpu_model(), 'kind': 'port (oracle/)',
+                           'what': 'BASELINE.md section 2 pieces: CAM() of 6x3x224x224, ConvLSTMCell step 6x1000x7x7, fp32'}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -234,7 +266,13 @@ def main():
     ap.add_argument('--source', default='', help='decoded frame size HxW: include the PIL-exact Lanczos resize (K0) in the step')
     ap.add_argument('--static-only', action='store_true',
                     help='BASELINE config C2: the static path only (equi -> cube -> ResNet-50 -> CAM); no roofline object')
+    ap.add_argument('--cpu-anchor', action='store_true',
+                    help='no GPU: time the oracle on the pieces BASELINE.md section 2 timed with the reference itself '
+                         '(CAM of one cube, one ConvLSTM step) - the sanity anchor of the cpu_baseline leg')
     args = ap.parse_args()
+    if args.cpu_anchor:
+        print(json.dumps(cpu_anchor()))
+        return
 
     rank, world, local = cpdist.init_from_env()
     if world != args.gpus:

@@ -99,6 +99,12 @@ for v in variants:
             "            const unsigned char* As = lds + stage * G::WSTAGE;                                             \\\n            if (LAG) __builtin_amdgcn_s_setprio(2);                                                        \\\n")
         sub("            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;",
             "            if (LAG) __builtin_amdgcn_s_setprio(0);                                                        \\\n            stage = stage == G::NW - 1 ? 0 : stage + 1;                                                    \\\n            ++tap;")
+    if v == 'slab_f16emu':     # precision experiment: split-K partial sums rounded to fp16 before they are stored (still f32 slabs)
+        sub('store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);',
+            '{ for (int e_ = 0; e_ < 4; ++e_) v[e_] = (float)(_Float16)v[e_]; store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v); }')
+    if v == 'slab_bf16emu':
+        sub('store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);',
+            '{ for (int e_ = 0; e_ < 4; ++e_) v[e_] = __uint_as_float(((unsigned)f32_to_bf16(v[e_])) << 16); store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v); }')
     if v.startswith('clip_jh'):   # clip kernel: MFMA columns issued in the load half (0 = pure load / compute halves)
         sub('constexpr int CLIP_JH = 0;', 'constexpr int CLIP_JH = %d;' % int(v[7:]))
     if v == 'clip_nw7':        # clip kernel: seven weight stages
