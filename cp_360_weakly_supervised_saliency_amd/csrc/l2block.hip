@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     };
     u32x4 a3[2][4], r[PB];
     load_a3(w4, a3);
-    load_res(w4, r);
+    load_res(w4, r);                                           // (requested before conv2 instead, next to the patch DMAs: 2-4 % slower; +8 % in l1block)
     __syncthreads();                                           // the t tiles and the biases are complete
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {

@@ -24,7 +24,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    # CP360_DIST_FORCE_PG=1: create the process group even for one rank, so that the RCCL branch (init, all-gather,
+    # all-reduce, barrier with device_ids) can be exercised on a one-GPU box (tests/test_distributed_gpu.py)
+    force = os.environ.get('CP360_DIST_FORCE_PG') == '1' and 'RANK' in os.environ
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -46,7 +49,7 @@ def shard_clips(n_clips, rank, world):
 def gather_maps(local_maps, n_clips, rank, world):
     """local_maps: [len(shard_clips(...)), h, w] f32 on this rank's device.
     Returns [n_clips, h, w] on every rank, ordered by clip id (one all_gather)."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local_maps
     base, extra = divmod(n_clips, world)
     cap = base + (1 if extra else 0)

@@ -1,0 +1,28 @@
+"""The RCCL branch of dist.py on hardware.  A gpurun box has ONE GPU and RCCL refuses two ranks on one device, so
+the group is created for a single rank (CP360_DIST_FORCE_PG=1) through the real launcher: backend "nccl",
+init_process_group, all_gather_into_tensor, all_reduce(MAX) and barrier(device_ids=...) all run on the device.
+The multi-rank logic itself (sharding, ragged gathers, ordering) is covered on gloo in test_distributed_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rccl_single_rank_through_torchrun():
+    env = dict(os.environ, CP360_DIST_FORCE_PG='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', '29541',
+           os.path.join(REPO, 'tests', '_torchrun_worker.py'), '5']
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['backend'] == 'nccl' and d['device'].startswith('cuda')
+    assert d['gathered_equal_single_process'] and d['n_gpus'] == 1 and d['max_elapsed'] == 0.5
