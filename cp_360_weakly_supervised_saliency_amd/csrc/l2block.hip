@@ -39,8 +39,12 @@ template <int N_, int BAND_, int NB> struct L2Geom {
     static constexpr int PATCH_PX = (BAND + 2) * NP;         // 180 / 264
     static constexpr int PATCH_INST = PATCH_PX / 4;          // DMA instructions of 4 pixels x 256 B
     static constexpr int PATCH_LDS = PATCH_INST * 1024;      // 46,080 / 67,584
+    static constexpr int SLICE_LDS = ((PX * T_STRIDE + 1023) / 1024) * 1024;   // one 128-channel slice of `out` (NEXT variant)
+    static constexpr int OFF_SLICE = NB * PATCH_LDS;              // behind the patches / t tiles
+    static constexpr int OFF_BIAS_NEXT = OFF_SLICE + NB * SLICE_LDS;
     static constexpr int OFF_BIAS = NB * PATCH_LDS;
     static constexpr int LDS_BYTES = OFF_BIAS + (C + CO) * 4;
+    static constexpr int LDS_BYTES_NEXT = OFF_BIAS_NEXT + (C + CO + C) * 4;
     static_assert(PX % 16 == 0 && PATCH_PX % 4 == 0 && N % BAND == 0 && PX * T_STRIDE <= PATCH_LDS, "band geometry");
 };
 
@@ -110,15 +114,16 @@ __global__ __launch_bounds__(256) void l2_pack_kernel(const float* __restrict__ 
     else packed[idx] = f32_to_bf16(v);
 }
 
-template <typename T, int NB, int NV, int BANDV>
+template <typename T, int NB, int NV, int BANDV, bool NEXT>
 __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
-                                                         T* __restrict__ out) {
+                                                         T* __restrict__ out, const T* __restrict__ w1f,
+                                                         const float* __restrict__ bias1, T* __restrict__ out_next) {
     typedef L2Geom<NV, BANDV, NB> G;
     constexpr int N = G::N, NP = G::NP, BAND = G::BAND, PX = G::PX, PB = G::PB, PATCH_INST = G::PATCH_INST,
-                  PATCH_LDS = G::PATCH_LDS, OFF_BIAS = G::OFF_BIAS;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
+                  PATCH_LDS = G::PATCH_LDS, OFF_BIAS = NEXT ? G::OFF_BIAS_NEXT : G::OFF_BIAS;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NEXT ? G::LDS_BYTES_NEXT : G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half_wg = wave >> 2, w4 = wave & 3;              // band A / B of this workgroup, wave inside the band
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     // ---- stage 2: t = relu(conv2 + b2) -> the band's t tile (in place of its patch); biases -> LDS
     float* bias_s = reinterpret_cast<float*>(lds + OFF_BIAS);
     for (int i = tid; i < C + CO; i += 256 * NB) bias_s[i] = i < C ? (bias2 ? bias2[i] : 0.f) : bias3[i - C];
+    if (NEXT) for (int i = tid; i < C; i += 256 * NB) bias_s[C + CO + i] = bias1 ? bias1[i] : 0.f;
     {
         const int n = w4 * 32 + lchunk * 8;
         float bb[8];
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     load_a3(w4, a3);
     load_res(w4, r);                                           // (requested before conv2 instead, next to the patch DMAs: 2-4 % slower; +8 % in l1block)
     __syncthreads();                                           // the t tiles and the biases are complete
+    if constexpr (!NEXT) {
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int p = w4 + 4 * q;
@@ -281,6 +288,104 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
             for (int j = 0; j < PB; ++j) r[j] = rn[j];
         }
     }
+    } else {
+        // ---- NEXT: the same four passes, and the next block's conv1 (512 -> 128, + bn1 + relu) on the fly.  In pass q the four
+        // waves produce `out` channels 128q .. 128q+127 = K slice q of that convolution: the rounded 16-byte pieces also go
+        // to an LDS slice ([112 px][128 ch], the t tile's layout), and after a barrier wave w accumulates ITS 32 output
+        // channels over the slice (8 A fragments from L2, 28 B-fragment reads, 56 MFMAs).  Registers: no second set of
+        // conv3 fragments / residual pieces - both are re-requested right after their last use and land under the
+        // 56 MFMAs of the chained convolution.
+        unsigned char* slice = lds + G::OFF_SLICE + half_wg * G::SLICE_LDS;
+        f32x4 acc1[2][PB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < PB; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load_a1 = [&](int q, u32x4 (&a)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+                    a[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(w1f) +
+                                                                ((size_t)((w4 * 2 + rb) * 16 + 4 * q + kb) * 64 + lane) * 16);
+        };
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const int p = w4 + 4 * q;
+            u32x4 a1[2][4];
+            load_a1(q, a1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int j0 = 0; j0 < PB; j0 += 4) {
+                    u32x4 b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < PB)
+                            b[u] = *reinterpret_cast<const u32x4*>(patch + ((j0 + u) * 16 + lrow) * T_STRIDE + (kb * 4 + lchunk) * 16);
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (j0 + u < PB) mma<T>(acc[rb][j0 + u], a3[rb][kb], b[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (q < 3) load_a3(p + 4, a3);                         // a3 is dead: the next pass's fragments land under the chained MFMAs
+            const int n = p * 32 + lchunk * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + C + n), b1 = *reinterpret_cast<const f32x4*>(bias_s + C + n + 4);
+            if (q > 0) __syncthreads();                            // every wave is done reading the previous slice
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                float v[8], rv[8];
+                unpack8(r[j], rv, T());
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[0][j][e] + b0[e] + rv[e], 0.f);
+                    v[4 + e] = fmaxf(acc[1][j][e] + b1[e] + rv[4 + e], 0.f);
+                }
+                const u32x4 o = pack8(v, T());
+                *reinterpret_cast<u32x4*>(out + (pix0 + j * 16 + lrow) * CO + n) = o;
+                *reinterpret_cast<u32x4*>(slice + (j * 16 + lrow) * T_STRIDE + (w4 * 32 + lchunk * 8) * 2) = o;
+            }
+            if (q < 3) load_res(p + 4, r);                         // r is dead too
+            __syncthreads();                                       // the slice is complete
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+                for (int j0 = 0; j0 < PB; j0 += 4) {
+                    u32x4 b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u < PB)
+                            b[u] = *reinterpret_cast<const u32x4*>(slice + ((j0 + u) * 16 + lrow) * T_STRIDE + (kb * 4 + lchunk) * 16);
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (j0 + u < PB) mma<T>(acc1[rb][j0 + u], a1[rb][kb], b[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // mid' = relu(conv1 + b1), one rounding, 16-byte stores ([px][128 ch])
+        const int n1 = w4 * 32 + lchunk * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias_s + C + CO + n1), c1 = *reinterpret_cast<const f32x4*>(bias_s + C + CO + n1 + 4);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(acc1[0][j][e] + c0[e], 0.f);
+                v[4 + e] = fmaxf(acc1[1][j][e] + c1[e], 0.f);
+            }
+            *reinterpret_cast<u32x4*>(out_next + (pix0 + j * 16 + lrow) * C + n1) = pack8(v, T());
+        }
+    }
 }
 
 extern "C" size_t cp360_l2block_packed_bytes(int dtype) {
@@ -301,25 +406,28 @@ extern "C" int cp360_l2block_pack_weights(int dtype, const float* w_oihw, const 
     return CP360_OK;
 }
 
-extern "C" int cp360_l2block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
-                                     const void* w3_frags, const float* bias3, const void* residual, void* out,
-                                     int n_img, int face, void* stream) {
+static int l2block_launch(int dtype, const void* mid, const void* w2_packed, const float* bias2, const void* w3_frags,
+                          const float* bias3, const void* residual, void* out, const void* w1_frags, const float* bias1,
+                          void* out_next, int n_img, int face, void* stream) {
     if (!mid || !w2_packed || !w3_frags || !bias3 || !residual || !out) return CP360_ERR_NULL;
     if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
     if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
     if (face != 28 && face != 64) return CP360_ERR_UNSUPPORTED;
+    if (out_next && face != 28) return CP360_ERR_UNSUPPORTED;      // the chained conv1 exists for 28x28 faces only
     if ((long long)n_img * face * face * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     static const int nb_env = []() { const char* e = getenv("CP360_L2_BANDS"); return e ? atoi(e) : 1; }();   // A/B switch
-    const int nb = (nb_env == 2 && face == 28) ? 2 : 1;
-#define CP360_L2B(TT, NBV, NV, BV)                                                                               \
-    hipLaunchKernelGGL((l2block_kernel<TT, NBV, NV, BV>), dim3((unsigned)(n_img * (NV / BV) / NBV)), dim3(256 * NBV), 0, st, \
-                       (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out)
-#define CP360_L2B_T(TT)                                      \
-    {                                                        \
-        if (face == 64) CP360_L2B(TT, 1, 64, 2);             \
-        else if (nb == 2) CP360_L2B(TT, 2, 28, 4);           \
-        else CP360_L2B(TT, 1, 28, 4);                        \
+    const int nb = (nb_env == 2 && face == 28 && !out_next) ? 2 : 1;
+#define CP360_L2B(TT, NBV, NV, BV, NX)                                                                               \
+    hipLaunchKernelGGL((l2block_kernel<TT, NBV, NV, BV, NX>), dim3((unsigned)(n_img * (NV / BV) / NBV)), dim3(256 * NBV), 0, st, \
+                       (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out, \
+                       (const TT*)w1_frags, bias1, (TT*)out_next)
+#define CP360_L2B_T(TT)                                             \
+    {                                                               \
+        if (out_next) CP360_L2B(TT, 1, 28, 4, true);                \
+        else if (face == 64) CP360_L2B(TT, 1, 64, 2, false);        \
+        else if (nb == 2) CP360_L2B(TT, 2, 28, 4, false);           \
+        else CP360_L2B(TT, 1, 28, 4, false);                        \
     }
     if (dtype == CP360_BF16) CP360_L2B_T(bf16_raw)
     else if (dtype == CP360_F16) CP360_L2B_T(f16_raw)
@@ -329,4 +437,20 @@ extern "C" int cp360_l2block_forward(int dtype, const void* mid, const void* w2_
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();
     return CP360_OK;
+}
+
+extern "C" int cp360_l2block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                                     const void* w3_frags, const float* bias3, const void* residual, void* out,
+                                     int n_img, int face, void* stream) {
+    return l2block_launch(dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, nullptr, nullptr, nullptr, n_img,
+                          face, stream);
+}
+
+extern "C" int cp360_l2block_forward_next(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                                          const void* w3_frags, const float* bias3, const void* residual, void* out,
+                                          const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
+                                          void* stream) {
+    if (!w1_frags || !out_next) return CP360_ERR_NULL;
+    return l2block_launch(dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, w1_frags, bias1, out_next, n_img,
+                          face, stream);
 }

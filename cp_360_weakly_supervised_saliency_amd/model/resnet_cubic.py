@@ -27,6 +27,7 @@ __all__ = ['ResNet', 'Bottleneck', 'resnet50']
 FUSE_DOWNSAMPLE = True
 FUSE_LAYER1 = True
 FUSE_LAYER2 = True
+FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
 
 
 
@@ -243,10 +244,20 @@ class ResNet(nn.Module):
         stamp = _stamp(self.layer2, (self.precision,))
         if getattr(self, '_l2', None) is None or stamp != self._l2_stamp:
             c = lambda conv, bn: (conv.weight,) + _fold_bn(bn)
-            self._l2 = [ops.L2Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), dt, self.conv1.weight.device) for b in blks[1:]]
+            ident = blks[1:]
+            self._l2 = [ops.L2Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), dt, self.conv1.weight.device,
+                                    next_conv1=c(ident[k + 1].conv1, ident[k + 1].bn1) if k + 1 < len(ident) else None)
+                        for k, b in enumerate(ident)]
             self._l2_stamp = stamp
-        for blk, tail in zip(blks[1:], self._l2):
-            x = tail(blk._plans()['c1'](x), x)
+        chain = FUSE_LAYER2_NEXT and x.shape[1] == 28          # the next block's conv1 rides on the tail (28x28 faces)
+        mid = None
+        for k, (blk, tail) in enumerate(zip(blks[1:], self._l2)):
+            if mid is None:
+                mid = blk._plans()['c1'](x)
+            if chain and tail.w1 is not None:
+                x, mid = tail(mid, x)
+            else:
+                x, mid = tail(mid, x, chain=False), None
         return x
 
     def features_nhwc(self, x_nhwc4, padded=False):

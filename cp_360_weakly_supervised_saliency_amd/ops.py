@@ -492,9 +492,10 @@ class L1Block:
 
 class L2Block:
     """K3e (csrc/l2block.hip): the tail of a layer2 identity Bottleneck as ONE launch - conv2 + bn2 + relu ->
-    conv3 + bn3 + residual + relu.  16-bit types, 28x28 faces.  (weight, bn scale, bn bias) triples."""
+    conv3 + bn3 + residual + relu (-> the next identity block's conv1 + bn1 + relu when `next_conv1` is given, 28x28
+    faces).  16-bit types, 28x28 / 64x64 faces.  (weight, bn scale, bn bias) triples."""
 
-    def __init__(self, conv2, conv3, dtype=torch.float16, device='cuda'):
+    def __init__(self, conv2, conv3, dtype=torch.float16, device='cuda', next_conv1=None):
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("L2Block runs in fp16 / bf16")
         self.dtype, self.device = dtype, torch.device(device)
@@ -509,9 +510,17 @@ class L2Block:
         self.b2 = f32(b2)
         self.w3 = frag_pack_1x1(w3, s3, dtype, 0, self.device)
         self.b3 = f32(b3)
+        self.w1 = self.b1 = None
+        if next_conv1 is not None:
+            w1, s1, b1 = next_conv1
+            if tuple(w1.shape[:2]) != (128, 512):
+                raise ValueError("the chained conv1 is 512->128")
+            self.w1 = frag_pack_1x1(w1, s1, dtype, 0, self.device)
+            self.b1 = f32(b1)
 
-    def __call__(self, mid, residual):
-        """mid [n_img, n, n, 128], residual [n_img, n, n, 512] -> out [n_img, n, n, 512]; n = 28 (cube 224) or 64 (cube 512)."""
+    def __call__(self, mid, residual, chain=True):
+        """mid [n_img, n, n, 128], residual [n_img, n, n, 512] -> out [n_img, n, n, 512]; n = 28 (cube 224) or 64 (cube 512).
+        With `next_conv1` (and 28x28 faces, chain=True): returns (out, next conv1's output [n_img, 28, 28, 128])."""
         require_gpu(mid, residual)
         n_img, n = mid.shape[0], mid.shape[1]
         if n not in (28, 64):
@@ -521,6 +530,14 @@ class L2Block:
         if mid.shape[3] != 128 or residual.shape[3] != 512:
             raise ValueError("dense NHWC tensors only")
         out = torch.empty((n_img, n, n, 512), dtype=self.dtype, device=mid.device)
+        if self.w1 is not None and chain:
+            if n != 28:
+                raise ValueError("the chained conv1 exists for 28x28 faces")
+            nxt = torch.empty((n_img, n, n, 128), dtype=self.dtype, device=mid.device)
+            check(lib().cp360_l2block_forward_next(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
+                                                   ptr(self.b3), ptr(residual), ptr(out), ptr(self.w1), ptr(self.b1), ptr(nxt),
+                                                   n_img, n, stream()))
+            return out, nxt
         check(lib().cp360_l2block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
                                           ptr(self.b3), ptr(residual), ptr(out), n_img, n, stream()))
         return out

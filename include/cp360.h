@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 207
+#define CP360_VERSION 208
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -303,6 +303,13 @@ int cp360_l2block_pack_weights(int dtype, const float* w_oihw, const float* scal
 int cp360_l2block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
                           const void* w3_frags, const float* bias3, const void* residual, void* out,
                           int n_img, int face, void* stream);
+/* The same launch also computing the NEXT identity block's conv1 (1x1, 512 -> 128) + bn1 + relu
+ * (model/resnet_cubic.py:88-90) from the output pieces while they are on the chip (28x28 faces only):
+ *   w1_frags = cp360_frag_pack_1x1(w1 [128, 512], order 0), bias1 f32 [128] or NULL, out_next [n_img, 28, 28, 128]. */
+int cp360_l2block_forward_next(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                               const void* w3_frags, const float* bias3, const void* residual, void* out,
+                               const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
+                               void* stream);
 
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),

@@ -333,8 +333,9 @@ def test_layer2_fused_tail_kernel_cube512_faces(prec):
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 @pytest.mark.parametrize('n_img', [6, 12])
 def test_layer2_fused_tail_kernel(prec, n_img):
-    """K3e (csrc/l2block.hip): layer2 with conv2 -> conv3 + residual of the identity blocks in one launch vs the
-    per-convolution path and vs torch-CPU (resnet_cubic.py:85-106)."""
+    """K3e (csrc/l2block.hip): layer2 with conv2 -> conv3 + residual (-> the next block's conv1) of the identity
+    blocks in one launch vs the per-convolution path, vs the tails without the chained conv1, and vs torch-CPU
+    (resnet_cubic.py:85-106)."""
     from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
     from oracle import o_resnet
     dt = _TDT[prec]
@@ -348,6 +349,12 @@ def test_layer2_fused_tail_kernel(prec, n_img):
         rc.FUSE_LAYER2 = True
     assert got.shape == (n_img, 28, 28, 512)
     assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    rc.FUSE_LAYER2_NEXT = False            # the tails without the chained conv1 of the next block
+    try:
+        unchained = m.layer2_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_LAYER2_NEXT = True
+    assert rel_err(got, unchained) <= _TOL[prec], rel_err(got, unchained)
     sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
     xc = x.float().cpu().permute(0, 3, 1, 2).contiguous()
     with torch.no_grad():
