@@ -1,8 +1,10 @@
-// K3e: the tail of a layer2 identity Bottleneck in ONE kernel (16-bit types; 28x28 faces = cube 224, 64x64 = cube 512):
+// K3e: the tail of a layer2 / layer3 identity Bottleneck in ONE kernel (16-bit types):
 //
-//   mid [.,28,28,128] --CubePad(1)+conv3x3 128->128 +bn2+relu--> t --conv1x1 128->512 +bn3 + residual + relu--> out
+//   mid [.,n,n,C] --CubePad(1)+conv3x3 C->C +bn2+relu--> t --conv1x1 C->4C +bn3 + residual + relu--> out
 //
-// (conv2 / conv3 / residual add of model/resnet_cubic.py:85-106 for layer2's blocks 1-3).  Separately these are a
+// (conv2 / conv3 / residual add of model/resnet_cubic.py:85-106), for layer2's blocks 1-3 (C = 128; 28x28 faces =
+// cube 224, 64x64 = cube 512) and layer3's blocks 1-5 (C = 256; 14x14 faces = cube 224).  The text below describes the
+// layer2 geometry; layer3's differences are listed at BtGeom.  Separately these are a
 // generic implicit GEMM that re-gathers its im2col rows once per tap (conv2, 0.15 ms per block for 64 frames) and
 // an HBM-bound 1x1 (conv3, 0.15 ms) with t making a round trip through HBM in between.  Here, as in l1block.hip:
 //   * a workgroup (8 waves) owns TWO bands of 4 output rows (112 pixels = 7 MFMA pixel blocks each, no padding
@@ -27,25 +29,40 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
-constexpr int C = 128, CO = 512;
-constexpr int W_STEP = C * 128;                              // 16 KiB of conv2 weights per half tap (16 fragments)
-constexpr int T_STRIDE = C * 2 + 16;                         // 272-byte pixel stride of the t tile
-// Face size N, BAND output rows per band (4 waves): 28x28 faces (cube 224) -> 4 rows = 112 pixels = 7 pixel blocks;
-// 64x64 faces (cube 512, BASELINE config C5) -> 2 rows = 128 pixels = 8 blocks.  NB = bands per workgroup.
-template <int N_, int BAND_, int NB> struct L2Geom {
-    static constexpr int N = N_, BAND = BAND_, NP = N + 2;
-    static constexpr int PX = BAND * N;                      // output pixels per band (consecutive in memory)
-    static constexpr int PB = PX / 16;
-    static constexpr int PATCH_PX = (BAND + 2) * NP;         // 180 / 264
-    static constexpr int PATCH_INST = PATCH_PX / 4;          // DMA instructions of 4 pixels x 256 B
-    static constexpr int PATCH_LDS = PATCH_INST * 1024;      // 46,080 / 67,584
+constexpr int W_STEP = 16 * 1024;                            // conv2 weights per step: 4 fragments for each of the 4 waves
+// Channels C (mid) -> CO = 4 C (out), face size N, BAND output rows per band (4 waves), NB bands per workgroup.
+//   layer2 (C = 128): 28x28 faces -> 4 rows = 112 pixels = 7 pixel blocks; 64x64 faces (cube 512, BASELINE config C5) ->
+//     2 rows = 128 pixels = 8 blocks.  A wave owns 32 conv2 channels (2 row blocks); a step = half a tap (K = 64).
+//   layer3 (C = 256): 14x14 faces -> 7 rows = 98 pixels in 7 blocks (the last 14 pixel slots are padding: they read
+//     pixel 97 again and store nothing).  A wave owns 2 x 32 conv2 channels, computed one after the other (HC = 2
+//     channel halves: the accumulators of 64 channels x 7 blocks do not fit next to the fragment prefetch); the first
+//     half's rounded t pieces wait in registers, because the t tile replaces the patch the second half still reads;
+//     36 steps per half; conv3's K = 256 runs as two half passes of 4 k-blocks; pixels are 512 bytes.
+template <int C_, int N_, int BAND_, int NB> struct BtGeom {
+    static constexpr int C = C_, CO = 4 * C_, N = N_, BAND = BAND_, NP = N + 2;
+    static constexpr int PXB = C * 2;                        // bytes per pixel
+    static constexpr int CH16 = PXB / 16;                    // 16-byte chunks per pixel (16 / 32)
+    static constexpr int PPI = 1024 / PXB;                   // pixels per DMA instruction (4 / 2)
+    static constexpr int PXV = BAND * N;                     // output pixels per band (consecutive in memory)
+    static constexpr int PB = (PXV + 15) / 16, PX = PB * 16;
+    static constexpr int PATCH_PX = (BAND + 2) * NP;         // 180 / 264 / 144
+    static constexpr int PATCH_INST = PATCH_PX / PPI;
+    static constexpr int PATCH_LDS = PATCH_INST * 1024;      // 46,080 / 67,584 / 73,728
+    static constexpr int T_STRIDE = PXB + 16;                // pixel stride of the t tile (272 / 528)
+    static constexpr int RBW = 2, KK = 2;                    // conv2: row blocks per wave and channel half, k-blocks per step
+    static constexpr int HC = C / 128;                       // channel halves (1 / 2)
+    static constexpr int SPT = C / 64;                       // steps per tap (2 / 4)
+    static constexpr int STEPS = 9 * SPT;                    // per channel half: 18 / 36
+    static constexpr int KB3 = C / 32, H3 = KB3 / 4;         // conv3: k-blocks, half passes per pass (1 / 2)
+    static constexpr int PASSES = CO / 128;                  // conv3 passes of 32 channels per wave (4 / 8)
     static constexpr int SLICE_LDS = ((PX * T_STRIDE + 1023) / 1024) * 1024;   // one 128-channel slice of `out` (NEXT variant)
     static constexpr int OFF_SLICE = NB * PATCH_LDS;              // behind the patches / t tiles
     static constexpr int OFF_BIAS_NEXT = OFF_SLICE + NB * SLICE_LDS;
     static constexpr int OFF_BIAS = NB * PATCH_LDS;
     static constexpr int LDS_BYTES = OFF_BIAS + (C + CO) * 4;
     static constexpr int LDS_BYTES_NEXT = OFF_BIAS_NEXT + (C + CO + C) * 4;
-    static_assert(PX % 16 == 0 && PATCH_PX % 4 == 0 && N % BAND == 0 && PX * T_STRIDE <= PATCH_LDS, "band geometry");
+    static_assert(PATCH_PX % PPI == 0 && N % BAND == 0 && PX * T_STRIDE <= PATCH_LDS && KB3 % 4 == 0,
+                  "band geometry");
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
@@ -98,31 +115,38 @@ __device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
 __host__ __device__ __forceinline__ int row_chan(int R) { return (R & ~31) + ((R >> 2) & 3) * 8 + ((R >> 4) & 1) * 4 + (R & 3); }
 }  // namespace
 
-// conv2 weights [128, 128, 3, 3] (times scale) -> MFMA A fragments [step s = tap * 2 + half][row block 8][kk 2]
-// [lane][8]: lane l holds row (l & 15) of the block (rows in acc_chan order), channels half*64 + kk*32 + (l>>4)*8 ..+7
-template <typename T>
-__global__ __launch_bounds__(256) void l2_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+// conv2 weights [C, C, 3, 3] (times scale) -> MFMA A fragments [channel half hc][step s = tap * SPT + sub][wave 4][i 2][kk 2]
+// [lane][8]: row block (hc * 4 + wave) * 2 + i, lane l holds row (l & 15) of it (rows in acc_chan order), channels
+// (sub * 2 + kk) * 32 + (l>>4)*8 ..+7 of the tap
+template <typename T, int C>
+__global__ __launch_bounds__(256) void bt_pack_kernel(const float* __restrict__ w, const float* __restrict__ scale,
                                                       T* __restrict__ packed) {
+    constexpr int SPT = C / 64, STEPS = 9 * SPT;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 9 * C * C) return;
-    const int e = idx & 7, lane = (idx >> 3) & 63, kk = (idx >> 9) & 1, rb = (idx >> 10) & 7, st = idx >> 13;
-    const int tap = st >> 1, half = st & 1;
-    const int n = row_chan(rb * 16 + (lane & 15));
-    const int c = half * 64 + kk * 32 + (lane >> 4) * 8 + e;
+    const int e = idx & 7, lane = (idx >> 3) & 63, kk = (idx >> 9) & 1, i = (idx >> 10) & 1, wv = (idx >> 11) & 3;
+    const int rest = idx >> 13;
+    const int st = rest % STEPS, hc = rest / STEPS;
+    const int tap = st / SPT, sub = st - tap * SPT;
+    const int n = row_chan(((hc * 4 + wv) * 2 + i) * 16 + (lane & 15));
+    const int c = (sub * 2 + kk) * 32 + (lane >> 4) * 8 + e;
     const float v = w[((size_t)n * C + c) * 9 + tap] * (scale ? scale[n] : 1.f);
     if constexpr (__is_same(T, f16_raw)) packed[idx] = (f16_raw)v;
     else packed[idx] = f32_to_bf16(v);
 }
 
-template <typename T, int NB, int NV, int BANDV, bool NEXT>
+template <typename T, int CV, int NB, int NV, int BANDV, bool NEXT>
 __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
                                                          T* __restrict__ out, const T* __restrict__ w1f,
                                                          const float* __restrict__ bias1, T* __restrict__ out_next) {
-    typedef L2Geom<NV, BANDV, NB> G;
-    constexpr int N = G::N, NP = G::NP, BAND = G::BAND, PX = G::PX, PB = G::PB, PATCH_INST = G::PATCH_INST,
-                  PATCH_LDS = G::PATCH_LDS, OFF_BIAS = NEXT ? G::OFF_BIAS_NEXT : G::OFF_BIAS;
+    typedef BtGeom<CV, NV, BANDV, NB> G;
+    constexpr int C = G::C, CO = G::CO, N = G::N, NP = G::NP, BAND = G::BAND, PXV = G::PXV, PB = G::PB,
+                  PATCH_INST = G::PATCH_INST, PATCH_LDS = G::PATCH_LDS, T_STRIDE = G::T_STRIDE, PXB = G::PXB, RBW = G::RBW,
+                  KK = G::KK, HC = G::HC, SPT = G::SPT, STEPS = G::STEPS, KB3 = G::KB3, H3 = G::H3, PASSES = G::PASSES,
+                  OFF_BIAS = NEXT ? G::OFF_BIAS_NEXT : G::OFF_BIAS;
+    static_assert(!NEXT || CV == 128, "the chained conv1 exists for layer2");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NEXT ? G::LDS_BYTES_NEXT : G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,18 +157,18 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     const int grp = img / 6, f = img - grp * 6;
     const CubePadGeom geom{N, 1, 1, 1, 1};
     const int lrow = lane & 15, lchunk = lane >> 4;
-    const size_t pix0 = (size_t)gband * PX;                    // the band's first pixel (pixels of a band are consecutive)
+    const size_t pix0 = (size_t)gband * PXV;                   // the band's first pixel (pixels of a band are consecutive)
     unsigned char* patch = lds + half_wg * PATCH_LDS;
 
-    // ---- stage 1: gather the band's padded pixels: instruction i = patch pixels 4i .. 4i+3, 256 B each
+    // ---- stage 1: gather the band's padded pixels: instruction i = patch pixels PPI i .. PPI i + PPI - 1 (4 x 256 B / 2 x 512 B)
     {
         const T* xg = x + (size_t)grp * 6 * N * N * C;
 #pragma unroll 1
         for (int inst = w4; inst < PATCH_INST; inst += 4) {
-            const int q = inst * 4 + (lane >> 4);
+            const int q = inst * G::PPI + lane / G::CH16;
             const int pr = q / NP, pc = q - pr * NP;
             const int sp = cubepad_src(f, BAND * band + pr, pc, geom);
-            const T* src = xg + (size_t)sp * C + (((lane & 15) ^ (q & 15)) << 3);
+            const T* src = xg + (size_t)sp * C + (((lane & (G::CH16 - 1)) ^ (q & 15)) << 3);
             glds16(src, __builtin_amdgcn_readfirstlane(lds_base + half_wg * PATCH_LDS + inst * 1024));
         }
     }
@@ -152,140 +176,185 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     // fragments of this wave's row pair): ~96 KiB in flight per CU and no barrier in the whole stage - a ring
     // in LDS (3 x 16 KiB, 2 steps ahead) left the stage waiting on L2 latency at every step (0.25 -> 0.17 ms)
     const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk2);
-    auto load_a = [&](int s, u32x4 (&a)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                a[i][kk] = *reinterpret_cast<const u32x4*>(wb + (size_t)s * W_STEP + (((w4 * 2 + i) * 2 + kk) * 64 + lane) * 16);
-    };
     constexpr int DEPTH = 3;
-    u32x4 aq[DEPTH + 1][2][2];
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s) load_a(s, aq[s]);
-
     int pbase[PB];                                             // patch pixel (tap 0, 0) of this lane's pixel in block j
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        const int pl = j * 16 + lrow, r = pl / N;
+        const int pl = min(j * 16 + lrow, PXV - 1), r = pl / N;      // (padding slots of a ragged band read its last pixel)
         pbase[j] = r * NP + (pl - r * N);
     }
-    f32x4 acc[2][PB];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the patch DMAs (and the first fragments)
-    __syncthreads();
-
-#pragma unroll
-    for (int s = 0; s < 18; ++s) {
-        if (s + DEPTH < 18) load_a(s + DEPTH, aq[(s + DEPTH) % (DEPTH + 1)]);
-        const int tap = s >> 1, half = s & 1;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int poff = ky * NP + kx;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            u32x4 b[PB];
-#pragma unroll
-            for (int j = 0; j < PB; ++j) {
-                const int p = pbase[j] + poff;
-                b[j] = *reinterpret_cast<const u32x4*>(patch + p * 256 + ((((half * 2 + kk) * 4 + lchunk) ^ (p & 15)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < PB; ++j) mma<T>(acc[i][j], aq[s % (DEPTH + 1)][i][kk], b[j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();                                           // every wave is done with the patches
-    // ---- stage 2: t = relu(conv2 + b2) -> the band's t tile (in place of its patch); biases -> LDS
+    f32x4 acc[RBW][PB];
+    u32x4 tkeep[HC > 1 ? PB : 1];                              // first channel half's t pieces (HC = 2)
     float* bias_s = reinterpret_cast<float*>(lds + OFF_BIAS);
     for (int i = tid; i < C + CO; i += 256 * NB) bias_s[i] = i < C ? (bias2 ? bias2[i] : 0.f) : bias3[i - C];
     if (NEXT) for (int i = tid; i < C; i += 256 * NB) bias_s[C + CO + i] = bias1 ? bias1[i] : 0.f;
-    {
-        const int n = w4 * 32 + lchunk * 8;
-        float bb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bb[e] = bias2 ? bias2[n + e] : 0.f;
+    for (int hc = 0; hc < HC; ++hc) {
+        u32x4 aq[DEPTH + 1][RBW][KK];
+        const unsigned char* wh = wb + (size_t)hc * STEPS * W_STEP;
+        auto load_a = [&](int s, u32x4 (&a)[RBW][KK]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            float v[8];
+            for (int i = 0; i < RBW; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = fmaxf(acc[0][j][e] + bb[e], 0.f);
-                v[4 + e] = fmaxf(acc[1][j][e] + bb[4 + e], 0.f);
+                for (int kk = 0; kk < KK; ++kk)
+                    a[i][kk] = *reinterpret_cast<const u32x4*>(wh + (size_t)s * W_STEP + (((w4 * RBW + i) * KK + kk) * 64 + lane) * 16);
+        };
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) load_a(s, aq[s]);
+#pragma unroll
+        for (int i = 0; i < RBW; ++i)
+#pragma unroll
+            for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int JG = HC > 1 ? 4 : PB;                    // (two channel halves: the kept t pieces leave room for 4 B fragments at a time)
+        if (hc == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch DMAs (and the first fragments)
+            __syncthreads();
+        }
+#define CP360_BT_STEP(S, SLOT, POFF, SUB)                                                                     \
+        {                                                                                                     \
+            if ((S) + DEPTH < STEPS) load_a((S) + DEPTH, aq[((SLOT) + DEPTH) % (DEPTH + 1)]);                 \
+            _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                                               \
+                _Pragma("unroll") for (int j0 = 0; j0 < PB; j0 += JG) {                                       \
+                    u32x4 b[JG];                                                                              \
+                    _Pragma("unroll") for (int u = 0; u < JG; ++u)                                            \
+                        if (j0 + u < PB) {                                                                    \
+                            const int p = pbase[j0 + u] + (POFF);                                             \
+                            b[u] = *reinterpret_cast<const u32x4*>(patch + p * PXB + (((((SUB) * KK + kk) * 4 + lchunk) ^ (p & 15)) << 4)); \
+                        }                                                                                     \
+                    _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                           \
+                        _Pragma("unroll") for (int u = 0; u < JG; ++u)                                        \
+                            if (j0 + u < PB) mma<T>(acc[i][j0 + u], aq[(SLOT) % (DEPTH + 1)][i][kk], b[u]);   \
+                    __builtin_amdgcn_sched_barrier(0);                                                        \
+                }                                                                                             \
+            }                                                                                                 \
+        }
+        if constexpr (SPT % (DEPTH + 1) == 0) {                // layer3: 4 steps per tap, the tap loop stays rolled
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int poff = ky * NP + kx;
+#pragma unroll
+                for (int sub = 0; sub < SPT; ++sub) CP360_BT_STEP(tap * SPT + sub, sub, poff, sub)
             }
-            *reinterpret_cast<u32x4*>(patch + (j * 16 + lrow) * T_STRIDE + n * 2) = pack8(v, T());
+        } else {
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int tap = s / SPT, sub = s - tap * SPT;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                CP360_BT_STEP(s, s, ky * NP + kx, sub)
+            }
+        }
+#undef CP360_BT_STEP
+        // ---- stage 2: t = relu(conv2 + b2), rounded once -> the band's t tile (in place of its patch, once every wave
+        // is done with the patch: after the LAST channel half)
+        if (hc == HC - 1) __syncthreads();
+        {
+            const int n = (hc * 4 + w4) * 32 + lchunk * 8;
+            float bb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = bias2 ? bias2[n + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[0][j][e] + bb[e], 0.f);
+                    v[4 + e] = fmaxf(acc[1][j][e] + bb[4 + e], 0.f);
+                }
+                const u32x4 o = pack8(v, T());
+                if (hc < HC - 1) tkeep[j] = o;
+                else *reinterpret_cast<u32x4*>(patch + (j * 16 + lrow) * T_STRIDE + n * 2) = o;
+            }
         }
     }
-    // ---- stage 3: conv3 (+ residual, ReLU): 4 passes of 32 output channels per wave
-    auto load_a3 = [&](int p, u32x4 (&a)[2][4]) __attribute__((always_inline)) {
+    if constexpr (HC > 1) {
+        const int n = w4 * 32 + lchunk * 8;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) *reinterpret_cast<u32x4*>(patch + (j * 16 + lrow) * T_STRIDE + n * 2) = tkeep[j];
+    }
+    // ---- stage 3: conv3 (+ residual, ReLU): PASSES passes of 32 output channels per wave, each H3 half passes of 4 k-blocks
+    auto load_a3 = [&](int u, u32x4 (&a)[2][4]) __attribute__((always_inline)) {     // unit u = pass * H3 + half
+        const int p = w4 + 4 * (u / H3), h = u % H3;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
                 a[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(w3f) +
-                                                            ((size_t)((p * 2 + rb) * 4 + kb) * 64 + lane) * 16);
+                                                            ((size_t)((p * 2 + rb) * KB3 + h * 4 + kb) * 64 + lane) * 16);
     };
+    // (stage 3's addresses are derived from an opaque copy of the lane's row: computed here, not hoisted above conv2 and
+    // spilled across it)
+    int lrow3 = lrow;
+    if constexpr (HC > 1) asm volatile("" : "+v"(lrow3));
+    int pres[PB];                                              // pixel of block j inside the band (padding slots: the last pixel)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) pres[j] = min(j * 16 + lrow3, PXV - 1);
     auto load_res = [&](int p, u32x4 (&r)[PB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            r[j] = *reinterpret_cast<const u32x4*>(res + (pix0 + j * 16 + lrow) * CO + p * 32 + lchunk * 8);
+            r[j] = *reinterpret_cast<const u32x4*>(res + (pix0 + pres[j]) * CO + p * 32 + lchunk * 8);
     };
     u32x4 a3[2][4], r[PB];
-    load_a3(w4, a3);
+    load_a3(0, a3);
     load_res(w4, r);                                           // (requested before conv2 instead, next to the patch DMAs: 2-4 % slower; +8 % in l1block)
     __syncthreads();                                           // the t tiles and the biases are complete
+    // conv3's accumulators: the first two rows of conv2's (dead by now)
     if constexpr (!NEXT) {
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
+    for (int u = 0; u < PASSES * H3; ++u) {
+        const int q = u / H3, h = u - q * H3;
         const int p = w4 + 4 * q;
         u32x4 a3n[2][4], rn[PB];
-        if (q < 3) load_a3(p + 4, a3n);
+        if (u + 1 < PASSES * H3) load_a3(u + 1, a3n);
+        if (h == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
             for (int j0 = 0; j0 < PB; j0 += 4) {               // pixel blocks in two groups (4 + 3): fewer live fragments
                 u32x4 b[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (j0 + u < PB)
-                        b[u] = *reinterpret_cast<const u32x4*>(patch + ((j0 + u) * 16 + lrow) * T_STRIDE + (kb * 4 + lchunk) * 16);
+                for (int v = 0; v < 4; ++v)
+                    if (j0 + v < PB)
+                        b[v] = *reinterpret_cast<const u32x4*>(patch + ((j0 + v) * 16 + lrow) * T_STRIDE + ((h * 4 + kb) * 4 + lchunk) * 16);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (j0 + u < PB) mma<T>(acc[rb][j0 + u], a3[rb][kb], b[u]);
+                    for (int v = 0; v < 4; ++v)
+                        if (j0 + v < PB) mma<T>(acc[rb][j0 + v], a3[rb][kb], b[v]);
                 __builtin_amdgcn_sched_barrier(0);             // keep the next group's fragment reads from being hoisted (spills)
             }
         }
-        if (q < 3) load_res(p + 4, rn);                        // lands under the next pass's MFMAs
-        const int n = p * 32 + lchunk * 8;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + C + n), b1 = *reinterpret_cast<const f32x4*>(bias_s + C + n + 4);
+        if (h == H3 - 1) {
+            if (q + 1 < PASSES) load_res(p + 4, rn);           // lands under the next pass's MFMAs
+            const int n = p * 32 + lchunk * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + C + n), b1 = *reinterpret_cast<const f32x4*>(bias_s + C + n + 4);
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            float v[8], rv[8];
-            unpack8(r[j], rv, T());
+            for (int j = 0; j < PB; ++j) {
+                float v[8], rv[8];
+                unpack8(r[j], rv, T());
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = fmaxf(acc[0][j][e] + b0[e] + rv[e], 0.f);
-                v[4 + e] = fmaxf(acc[1][j][e] + b1[e] + rv[4 + e], 0.f);
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[0][j][e] + b0[e] + rv[e], 0.f);
+                    v[4 + e] = fmaxf(acc[1][j][e] + b1[e] + rv[4 + e], 0.f);
+                }
+                if (PXV % 16 == 0 || j * 16 + lrow3 < PXV)
+                    *reinterpret_cast<u32x4*>(out + (pix0 + j * 16 + lrow3) * CO + n) = pack8(v, T());
             }
-            *reinterpret_cast<u32x4*>(out + (pix0 + j * 16 + lrow) * CO + n) = pack8(v, T());
+            if (q + 1 < PASSES) {
+#pragma unroll
+                for (int j = 0; j < PB; ++j) r[j] = rn[j];
+            }
         }
-        if (q < 3) {
+        if (u + 1 < PASSES * H3) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) a3[rb][kb] = a3n[rb][kb];
-#pragma unroll
-            for (int j = 0; j < PB; ++j) r[j] = rn[j];
         }
     }
     } else {
@@ -335,7 +404,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (q < 3) load_a3(p + 4, a3);                         // a3 is dead: the next pass's fragments land under the chained MFMAs
+            if (q < 3) load_a3(q + 1, a3);                        // a3 is dead: the next pass's fragments land under the chained MFMAs
             const int n = p * 32 + lchunk * 8;
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + C + n), b1 = *reinterpret_cast<const f32x4*>(bias_s + C + n + 4);
             if (q > 0) __syncthreads();                            // every wave is done reading the previous slice
@@ -349,7 +418,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                     v[4 + e] = fmaxf(acc[1][j][e] + b1[e] + rv[4 + e], 0.f);
                 }
                 const u32x4 o = pack8(v, T());
-                *reinterpret_cast<u32x4*>(out + (pix0 + j * 16 + lrow) * CO + n) = o;
+                *reinterpret_cast<u32x4*>(out + (pix0 + j * 16 + lrow3) * CO + n) = o;
                 *reinterpret_cast<u32x4*>(slice + (j * 16 + lrow) * T_STRIDE + (w4 * 32 + lchunk * 8) * 2) = o;
             }
             if (q < 3) load_res(p + 4, r);                         // r is dead too
@@ -383,51 +452,63 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                 v[e] = fmaxf(acc1[0][j][e] + c0[e], 0.f);
                 v[4 + e] = fmaxf(acc1[1][j][e] + c1[e], 0.f);
             }
-            *reinterpret_cast<u32x4*>(out_next + (pix0 + j * 16 + lrow) * C + n1) = pack8(v, T());
+            *reinterpret_cast<u32x4*>(out_next + (pix0 + j * 16 + lrow3) * C + n1) = pack8(v, T());
         }
     }
 }
 
-extern "C" size_t cp360_l2block_packed_bytes(int dtype) {
-    return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)18 * W_STEP : 0;
+static size_t bt_packed_bytes(int dtype, int c) {
+    return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)9 * c * c * 2 : 0;
 }
-
-extern "C" int cp360_l2block_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
+template <int C>
+static int bt_pack(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
     if (!w_oihw || !packed) return CP360_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const unsigned blocks = (9 * C * C + 255) / 256;
     if (dtype == CP360_BF16)
-        hipLaunchKernelGGL((l2_pack_kernel<bf16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (bf16_raw*)packed);
+        hipLaunchKernelGGL((bt_pack_kernel<bf16_raw, C>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (bf16_raw*)packed);
     else if (dtype == CP360_F16)
-        hipLaunchKernelGGL((l2_pack_kernel<f16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (f16_raw*)packed);
+        hipLaunchKernelGGL((bt_pack_kernel<f16_raw, C>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (f16_raw*)packed);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();
     return CP360_OK;
 }
 
-static int l2block_launch(int dtype, const void* mid, const void* w2_packed, const float* bias2, const void* w3_frags,
-                          const float* bias3, const void* residual, void* out, const void* w1_frags, const float* bias1,
-                          void* out_next, int n_img, int face, void* stream) {
+extern "C" size_t cp360_l2block_packed_bytes(int dtype) { return bt_packed_bytes(dtype, 128); }
+extern "C" size_t cp360_l3block_packed_bytes(int dtype) { return bt_packed_bytes(dtype, 256); }
+extern "C" int cp360_l2block_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
+    return bt_pack<128>(dtype, w_oihw, scale, packed, stream);
+}
+extern "C" int cp360_l3block_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream) {
+    return bt_pack<256>(dtype, w_oihw, scale, packed, stream);
+}
+
+// layer: 2 (C = 128; faces 28 / 64) or 3 (C = 256; faces 14)
+static int bt_launch(int layer, int dtype, const void* mid, const void* w2_packed, const float* bias2, const void* w3_frags,
+                     const float* bias3, const void* residual, void* out, const void* w1_frags, const float* bias1,
+                     void* out_next, int n_img, int face, void* stream) {
     if (!mid || !w2_packed || !w3_frags || !bias3 || !residual || !out) return CP360_ERR_NULL;
     if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
     if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
-    if (face != 28 && face != 64) return CP360_ERR_UNSUPPORTED;
-    if (out_next && face != 28) return CP360_ERR_UNSUPPORTED;      // the chained conv1 exists for 28x28 faces only
-    if ((long long)n_img * face * face * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    if (layer == 2 ? (face != 28 && face != 64) : face != 14) return CP360_ERR_UNSUPPORTED;
+    if (out_next && (layer != 2 || face != 28)) return CP360_ERR_UNSUPPORTED;   // the chained conv1: layer2, 28x28 faces
+    const int co = layer == 2 ? 512 : 1024;
+    if ((long long)n_img * face * face * co >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     static const int nb_env = []() { const char* e = getenv("CP360_L2_BANDS"); return e ? atoi(e) : 1; }();   // A/B switch
-    const int nb = (nb_env == 2 && face == 28 && !out_next) ? 2 : 1;
-#define CP360_L2B(TT, NBV, NV, BV, NX)                                                                               \
-    hipLaunchKernelGGL((l2block_kernel<TT, NBV, NV, BV, NX>), dim3((unsigned)(n_img * (NV / BV) / NBV)), dim3(256 * NBV), 0, st, \
+    const int nb = (nb_env == 2 && layer == 2 && face == 28 && !out_next) ? 2 : 1;
+#define CP360_L2B(TT, CV, NBV, NV, BV, NX)                                                                           \
+    hipLaunchKernelGGL((l2block_kernel<TT, CV, NBV, NV, BV, NX>), dim3((unsigned)(n_img * (NV / BV) / NBV)), dim3(256 * NBV), 0, st, \
                        (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out, \
                        (const TT*)w1_frags, bias1, (TT*)out_next)
-#define CP360_L2B_T(TT)                                             \
-    {                                                               \
-        if (out_next) CP360_L2B(TT, 1, 28, 4, true);                \
-        else if (face == 64) CP360_L2B(TT, 1, 64, 2, false);        \
-        else if (nb == 2) CP360_L2B(TT, 2, 28, 4, false);           \
-        else CP360_L2B(TT, 1, 28, 4, false);                        \
+#define CP360_L2B_T(TT)                                                  \
+    {                                                                    \
+        if (layer == 3) CP360_L2B(TT, 256, 1, 14, 7, false);             \
+        else if (out_next) CP360_L2B(TT, 128, 1, 28, 4, true);           \
+        else if (face == 64) CP360_L2B(TT, 128, 1, 64, 2, false);        \
+        else if (nb == 2) CP360_L2B(TT, 128, 2, 28, 4, false);           \
+        else CP360_L2B(TT, 128, 1, 28, 4, false);                        \
     }
     if (dtype == CP360_BF16) CP360_L2B_T(bf16_raw)
     else if (dtype == CP360_F16) CP360_L2B_T(f16_raw)
@@ -442,8 +523,8 @@ static int l2block_launch(int dtype, const void* mid, const void* w2_packed, con
 extern "C" int cp360_l2block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
                                      const void* w3_frags, const float* bias3, const void* residual, void* out,
                                      int n_img, int face, void* stream) {
-    return l2block_launch(dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, nullptr, nullptr, nullptr, n_img,
-                          face, stream);
+    return bt_launch(2, dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, nullptr, nullptr, nullptr, n_img, face,
+                     stream);
 }
 
 extern "C" int cp360_l2block_forward_next(int dtype, const void* mid, const void* w2_packed, const float* bias2,
@@ -451,6 +532,13 @@ extern "C" int cp360_l2block_forward_next(int dtype, const void* mid, const void
                                           const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
                                           void* stream) {
     if (!w1_frags || !out_next) return CP360_ERR_NULL;
-    return l2block_launch(dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, w1_frags, bias1, out_next, n_img,
-                          face, stream);
+    return bt_launch(2, dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, w1_frags, bias1, out_next, n_img, face,
+                     stream);
+}
+
+extern "C" int cp360_l3block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                                     const void* w3_frags, const float* bias3, const void* residual, void* out,
+                                     int n_img, int face, void* stream) {
+    return bt_launch(3, dtype, mid, w2_packed, bias2, w3_frags, bias3, residual, out, nullptr, nullptr, nullptr, n_img, face,
+                     stream);
 }

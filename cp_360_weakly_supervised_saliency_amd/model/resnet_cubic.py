@@ -27,6 +27,7 @@ __all__ = ['ResNet', 'Bottleneck', 'resnet50']
 FUSE_DOWNSAMPLE = True
 FUSE_LAYER1 = True
 FUSE_LAYER2 = True
+FUSE_LAYER3 = True
 FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
 
 
@@ -260,14 +261,35 @@ class ResNet(nn.Module):
                 x, mid = tail(mid, x, chain=False), None
         return x
 
+    def layer3_nhwc(self, x):
+        """layer3 on the fused path.  16-bit types at 14x14 output faces: the identity blocks run conv1 as a convolution
+        and conv2 -> conv3 + residual as ONE launch (csrc/l2block.hip at C = 256); the first (stride-2, downsample)
+        block stays on the per-convolution path."""
+        dt = _DTYPES[self.precision]
+        blks = list(self.layer3)
+        x = blks[0].forward_nhwc(x)
+        if not (FUSE_LAYER3 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] == 14
+                and all(b.downsample is None and b.stride == 1 for b in blks[1:])):
+            for blk in blks[1:]:
+                x = blk.forward_nhwc(x)
+            return x
+        stamp = _stamp(self.layer3, (self.precision,))
+        if getattr(self, '_l3', None) is None or stamp != self._l3_stamp:
+            c = lambda conv, bn: (conv.weight,) + _fold_bn(bn)
+            self._l3 = [ops.L3Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), dt, self.conv1.weight.device) for b in blks[1:]]
+            self._l3_stamp = stamp
+        for blk, tail in zip(blks[1:], self._l3):
+            x = tail(blk._plans()['c1'](x), x)
+        return x
+
     def features_nhwc(self, x_nhwc4, padded=False):
         """Fused path to layer4: [6N, H, W, 4] -> [6N, H/32, W/32, 2048]."""
         x = self.stem_nhwc(x_nhwc4, padded)
         x = self.layer1_nhwc(x)
         x = self.layer2_nhwc(x)
-        for layer in (self.layer3, self.layer4):
-            for blk in layer:
-                x = blk.forward_nhwc(x)
+        x = self.layer3_nhwc(x)
+        for blk in self.layer4:
+            x = blk.forward_nhwc(x)
         return x
 
     def forward(self, x):

@@ -543,6 +543,42 @@ class L2Block:
         return out
 
 
+class L3Block:
+    """K3e at layer3's geometry (csrc/l2block.hip, C = 256): the tail of a layer3 identity Bottleneck as ONE launch -
+    conv2 + bn2 + relu -> conv3 + bn3 + residual + relu.  16-bit types, 14x14 faces.  (weight, bn scale, bn bias) triples."""
+
+    def __init__(self, conv2, conv3, dtype=torch.float16, device='cuda'):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("L3Block runs in fp16 / bf16")
+        self.dtype, self.device = dtype, torch.device(device)
+        L, code = lib(), dtype_code(dtype)
+        f32 = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        w2, s2, b2 = conv2
+        w3, s3, b3 = conv3
+        if tuple(w2.shape) != (256, 256, 3, 3) or tuple(w3.shape[:2]) != (1024, 256):
+            raise ValueError("L3Block is layer3's geometry: conv2 256->256 3x3, conv3 256->1024 1x1")
+        self.w2 = torch.empty(L.cp360_l3block_packed_bytes(code), dtype=torch.uint8, device=self.device)
+        check(L.cp360_l3block_pack_weights(code, ptr(f32(w2)), ptr(f32(s2)), ptr(self.w2), stream()))
+        self.b2 = f32(b2)
+        self.w3 = frag_pack_1x1(w3, s3, dtype, 0, self.device)
+        self.b3 = f32(b3)
+
+    def __call__(self, mid, residual):
+        """mid [n_img, 14, 14, 256], residual [n_img, 14, 14, 1024] -> out [n_img, 14, 14, 1024]."""
+        require_gpu(mid, residual)
+        n_img, n = mid.shape[0], mid.shape[1]
+        if n != 14:
+            raise ValueError("L3Block handles 14x14 faces")
+        _check_buf('mid', mid, self.dtype, (n_img, n, n, 256))
+        _check_buf('residual', residual, self.dtype, (n_img, n, n, 1024))
+        if mid.shape[3] != 256 or residual.shape[3] != 1024:
+            raise ValueError("dense NHWC tensors only")
+        out = torch.empty((n_img, n, n, 1024), dtype=self.dtype, device=mid.device)
+        check(lib().cp360_l3block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
+                                          ptr(self.b3), ptr(residual), ptr(out), n_img, n, stream()))
+        return out
+
+
 def cubepad_maxpool3s2(x):
     """CubePad(1) + MaxPool2d(3, 2, 0) on NHWC (resnet_cubic.py:169-170)."""
     require_gpu(x)

@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 208
+#define CP360_VERSION 209
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -310,6 +310,17 @@ int cp360_l2block_forward_next(int dtype, const void* mid, const void* w2_packed
                                const void* w3_frags, const float* bias3, const void* residual, void* out,
                                const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
                                void* stream);
+
+/* The same kernel at layer3's geometry (csrc/l2block.hip, C = 256): conv2 (CubePad(1) + 3x3, 256 -> 256) + bn2 + relu ->
+ * conv3 (1x1, 256 -> 1024) + bn3 + identity residual + relu of layer3's identity Bottlenecks at cube size 224
+ * (14x14 faces: `face` = 14, anything else CP360_ERR_UNSUPPORTED).
+ *   mid [n_img, 14, 14, 256], w2_packed = cp360_l3block_pack_weights(w2 [256,256,3,3]), bias2 f32 [256],
+ *   w3_frags = cp360_frag_pack_1x1(w3 [1024, 256], order 0), bias3 f32 [1024], residual / out [n_img, 14, 14, 1024]. */
+size_t cp360_l3block_packed_bytes(int dtype);
+int cp360_l3block_pack_weights(int dtype, const float* w_oihw, const float* scale, void* packed, void* stream);
+int cp360_l3block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                          const void* w3_frags, const float* bias3, const void* residual, void* out,
+                          int n_img, int face, void* stream);
 
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),

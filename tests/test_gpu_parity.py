@@ -364,6 +364,34 @@ def test_layer2_fused_tail_kernel(prec, n_img):
     assert rel_err(got, want) <= 4 * _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n_img', [6, 12])
+def test_layer3_fused_tail_kernel(prec, n_img):
+    """K3e at layer3's geometry (csrc/l2block.hip, C = 256, 14x14 faces, bands of 7 rows = 98 pixels in 7 pixel blocks
+    with 14 padding slots): layer3 with conv2 -> conv3 + residual of the identity blocks in one launch vs the
+    per-convolution path and vs torch-CPU (resnet_cubic.py:85-106)."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    from oracle import o_resnet
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4900 + n_img, (n_img, 28, 28, 512), 0.0, 1.0))).to(DEV).to(dt)
+    got = m.layer3_nhwc(x).float().cpu().numpy()
+    rc.FUSE_LAYER3 = False
+    try:
+        sep = m.layer3_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_LAYER3 = True
+    assert got.shape == (n_img, 14, 14, 1024)
+    assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xc = x.float().cpu().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for b in range(6):
+            xc = o_resnet._bottleneck(xc, sdt, 'layer3.%d' % b, 2 if b == 0 else 1, b == 0)
+        want = xc.permute(0, 2, 3, 1).numpy()
+    assert rel_err(got, want) <= 6 * _TOL[prec], rel_err(got, want)
+
+
 @pytest.mark.parametrize('tile_px', [128, 256, 304])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('splits', [1, 3])
