@@ -10,8 +10,10 @@
 //   * a workgroup (8 waves) owns TWO bands of 4 output rows (112 pixels = 7 MFMA pixel blocks each, no padding
 //     columns: a band's pixels are consecutive in memory); waves 0-3 work on band A, waves 4-7 on band B;
 //   * stage 1 (conv2): each band's 6 x 30 cube-padded pixels (256 B each, 45 KB) are gathered ONCE by LDS-DMA through
-//     cubepad_src(); the nine taps read them there (pixel p's 16-byte chunk c sits at chunk c ^ (p & 15): 16
-//     consecutive pixels cover the 16 slots of the 256-byte bank row).  Wave w computes the 32-channel row pair
+//     cubepad_src(); the nine taps read them there (the 16-byte chunk c of patch pixel (row, col) sits at chunk
+//     c ^ ((row * N + col) & 15): the 16 pixels of an MFMA block are consecutive OUTPUT pixels, so this key runs through
+//     16 consecutive values for every tap - also where a block wraps from one face row to the next, where the patch
+//     index jumps by the two padding columns - and the 16 lanes cover the 16 slots of a bank row).  Wave w computes the 32-channel row pair
 //     (w & 3) for all 7 pixel blocks of its band; its A fragments (4 KiB per half tap) come from L2 straight into
 //     registers, three half taps ahead - no LDS ring and no barrier inside the stage;
 //   * stage 2: t = relu(conv2 + b2), rounded once, goes to LDS ([112 px][128 ch], 272-byte pixel stride) - the
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
             const int q = inst * G::PPI + lane / G::CH16;
             const int pr = q / NP, pc = q - pr * NP;
             const int sp = cubepad_src(f, BAND * band + pr, pc, geom);
-            const T* src = xg + (size_t)sp * C + (((lane & (G::CH16 - 1)) ^ (q & 15)) << 3);
+            const T* src = xg + (size_t)sp * C + (((lane & (G::CH16 - 1)) ^ ((pr * N + pc) & 15)) << 3);   // swizzle key: see the B reads
             glds16(src, __builtin_amdgcn_readfirstlane(lds_base + half_wg * PATCH_LDS + inst * 1024));
         }
     }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch DMAs (and the first fragments)
             __syncthreads();
         }
-#define CP360_BT_STEP(S, SLOT, POFF, SUB)                                                                     \
+#define CP360_BT_STEP(S, SLOT, POFF, KOFF, SUB)                                                                    \
         {                                                                                                     \
             if ((S) + DEPTH < STEPS) load_a((S) + DEPTH, aq[((SLOT) + DEPTH) % (DEPTH + 1)]);                 \
             _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                                               \
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                     _Pragma("unroll") for (int u = 0; u < JG; ++u)                                            \
                         if (j0 + u < PB) {                                                                    \
                             const int p = pbase[j0 + u] + (POFF);                                             \
-                            b[u] = *reinterpret_cast<const u32x4*>(patch + p * PXB + (((((SUB) * KK + kk) * 4 + lchunk) ^ (p & 15)) << 4)); \
+                            b[u] = *reinterpret_cast<const u32x4*>(patch + p * PXB + (((((SUB) * KK + kk) * 4 + lchunk) ^ ((lrow + (KOFF)) & 15)) << 4)); \
                         }                                                                                     \
                     _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                           \
                         _Pragma("unroll") for (int u = 0; u < JG; ++u)                                        \
@@ -234,14 +236,14 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                 const int ky = tap / 3, kx = tap - ky * 3;
                 const int poff = ky * NP + kx;
 #pragma unroll
-                for (int sub = 0; sub < SPT; ++sub) CP360_BT_STEP(tap * SPT + sub, sub, poff, sub)
+                for (int sub = 0; sub < SPT; ++sub) CP360_BT_STEP(tap * SPT + sub, sub, poff, ky * N + kx, sub)
             }
         } else {
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
                 const int tap = s / SPT, sub = s - tap * SPT;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                CP360_BT_STEP(s, s, ky * NP + kx, sub)
+                CP360_BT_STEP(s, s, ky * NP + kx, ky * N + kx, sub)
             }
         }
 #undef CP360_BT_STEP
@@ -457,6 +459,11 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     }
 }
 
+// (A wave-specialised persistent form of this kernel - waves 0-3 gather + conv2 of band i while waves 4-7 run conv3 +
+// residual + store of band i-1 from the t tile, two workgroup barriers per band - was built for layer3 and measured
+// bit-identical and no faster, 176 vs 175 us: each stage is latency-bound at the waves it has, so halving the waves per
+// stage doubles its time.  Stage ablations of the layer3 launch: gather + prologue 38 us, conv2 70 us (69 % of its
+// MFMA time), conv3 + residual + store 67 us = 4.6 TB/s; A fragments from hot lines -9 us, conflict-free B reads -5 us.)
 static size_t bt_packed_bytes(int dtype, int c) {
     return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)9 * c * c * 2 : 0;
 }
