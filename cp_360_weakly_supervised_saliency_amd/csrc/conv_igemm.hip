@@ -1771,7 +1771,14 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
     }();
     // (K of at least two 128-byte steps: at K = 64 elements the one-workgroup 256x304 tile measured faster)
     const int kbytes = (d->c_in + d->c_in2) * elem_bytes(d->dtype);
-    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && kbytes >= 256 && kbytes <= 1024) {
+    static const int ring2_kmax = []() {
+        // K of at most four 128-byte steps.  (Up to 1 KiB it used to take the HBM-bound 1x1 convolutions of layers 2-4;
+        // measured per launch, 64 frames: l2.0 conv3 + downsample (K = 768 B) 232 -> 199 us on the 256x304 ring, l3.0
+        // conv1 (1 KiB) 153 -> 124, l4 conv3 (1 KiB) 84 -> 71; at 512 B - l3 conv3 - the two tie.)  A/B switch.
+        const char* e = getenv("CP360_RING2_KMAX");
+        return e ? atoi(e) : 512;
+    }();
+    if (ring2 && d->dtype != CP360_F32 && d->kh * d->kw == 1 && kbytes >= 256 && kbytes <= ring2_kmax) {
         ConvPlan r2 = plan_candidate(d, 256, 128, 512, 1.25);
         r2.bm = 129;
         if (r2.cost < best.cost) best = r2;

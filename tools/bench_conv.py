@@ -38,6 +38,10 @@ shapes = [
     ('l4.conv2 3x3', 6 * F, 512, 512, 7, 3, 1, 1),
     ('l4.conv3 1x1', 6 * F, 512, 2048, 7, 1, 1, 0),
     ('cam 1x1     ', 6 * F, 2048, 1000, 7, 1, 1, 0),
+    ('l3.conv1 1x1', 6 * F, 1024, 256, 14, 1, 1, 0),
+    ('l4.conv1 1x1', 6 * F, 2048, 512, 7, 1, 1, 0),
+    ('l3.0conv1 1x1', 6 * F, 512, 256, 28, 1, 1, 0),
+    ('l4.0conv1 1x1', 6 * F, 1024, 512, 14, 1, 1, 0),
 ]
 for name, n_img, cin, cout, n, k, s, pad in shapes:
     if args.only and args.only not in name:
