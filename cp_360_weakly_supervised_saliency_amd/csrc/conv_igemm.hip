@@ -1312,6 +1312,30 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
             for (int k = 1; k < G::NW - 1; ++k)
                 if (nloc > k) { woff += WSTEP; issue_w(0, sb + k * G::WSTAGE); issue_w(1, sb + k * G::WSTAGE); }
         }
+        // ---- source-row table (built while the prologue's DMAs are in flight: ~2-3 us of address arithmetic under their
+        // HBM latency instead of in front of it): entry(tap, group, lane row, block j) = LDS byte offset (row * 64 +
+        // swizzle bits) inside the resident tile of the pixel that tap `tap` of tile row
+        // group*160 + j*16 + lrow reads (through CubePad); rows past the clip read row 0 (discarded).
+        {
+            unsigned short* tab = reinterpret_cast<unsigned short*>(lds + G::OFF_TAB);
+            const int n = p.h_in, nn = n * n;
+            const CubePadGeom geom{n, 1, 1, 1, 1};
+            for (int idx = tid; idx < 9 * 2 * 16 * 10; idx += 512) {
+                const int j = idx % 10, lr = (idx / 10) % 16, g = (idx / 160) % 2, t = idx / 320;
+                const int row = g * G::GROUP_ROWS + j * 16 + lr;
+                int src = 0;
+                if (FACE) {
+                    if (j < 8) src = ((row >> 4) + t / 3) * 18 + (row & 15) + t % 3;   // row of the padded 18x18 face
+                } else if (row < p.clip_rows && (g == 0 || j < 9)) {
+                    const int f = row / nn, rem = row - f * nn;
+                    const int y = rem / n, x = rem - y * n;
+                    src = cubepad_src(f, y + t / 3, x + t % 3, geom);          // pixel index inside the clip
+                }
+                tab[((t * 2 + g) * 16 + lr) * (G::TAB_ROW / 2) + j] =
+                    (unsigned short)(src * 64 + (clip_swz(src) << 4));
+            }
+            __syncthreads();
+        }
         load_ent(tap);
         decode();
         int stage = 0;
@@ -1450,29 +1474,6 @@ __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
         const int rest = w / p.mt;
         n0 = (rest % p.nt) * G::BN;
         split = rest / p.nt;
-    }
-    // ---- source-row table: entry(tap, group, lane row, block j) = LDS byte offset (row * 64 +
-    // swizzle bits) inside the resident tile of the pixel that tap `tap` of tile row
-    // group*160 + j*16 + lrow reads (through CubePad); rows past the clip read row 0 (discarded).
-    {
-        unsigned short* tab = reinterpret_cast<unsigned short*>(lds + G::OFF_TAB);
-        const int n = p.h_in, nn = n * n;
-        const CubePadGeom geom{n, 1, 1, 1, 1};
-        for (int idx = tid; idx < 9 * 2 * 16 * 10; idx += 512) {
-            const int j = idx % 10, lr = (idx / 10) % 16, g = (idx / 160) % 2, t = idx / 320;
-            const int row = g * G::GROUP_ROWS + j * 16 + lr;
-            int src = 0;
-            if (FACE) {
-                if (j < 8) src = ((row >> 4) + t / 3) * 18 + (row & 15) + t % 3;   // row of the padded 18x18 face
-            } else if (row < p.clip_rows && (g == 0 || j < 9)) {
-                const int f = row / nn, rem = row - f * nn;
-                const int y = rem / n, x = rem - y * n;
-                src = cubepad_src(f, y + t / 3, x + t % 3, geom);          // pixel index inside the clip
-            }
-            tab[((t * 2 + g) * 16 + lr) * (G::TAB_ROW / 2) + j] =
-                (unsigned short)(src * 64 + (clip_swz(src) << 4));
-        }
-        __syncthreads();
     }
     constexpr int JHC = CLIP_JH;                       // MFMA columns issued in the load half of a sub-step (see clip_body)
     if constexpr (FACE) {
