@@ -90,3 +90,9 @@ __host__ __device__ __forceinline__ int cubepad_src(int f, int i, int j, const C
     const int col = cs == 0 ? k : (cs == 1 ? e : (cs == 2 ? a : m));
     return (sf * n + row) * n + col;
 }
+
+// Traversal order of the launch being issued by this host thread (cp360_set_launch_order, include/cp360.h): 0 = work
+// items in ascending order, 1 = descending; in the alternating mode every call flips it.  Results never depend on it.
+// Defined in cubepad.hip; called once per launch by the kernels that honour it.
+int cp360_launch_reverse();
+

@@ -55,6 +55,7 @@ struct ConvK {
     int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
     int nt, mt, m_fast;
     int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
+    int reverse;                          // 1: work items in descending order (cp360_set_launch_order)
     int epi_direct;                       // 1: direct 16-byte epilogue, 0: LDS-staged epilogue
     int slab_rows;                        // 1: split-K slabs in packed-row column order (slab_col)
     // second source (cp360_conv_desc.c_in2 > 0): one extra 1x1 "tap" (index kh*kw, packed behind the others)
@@ -383,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK p) {
     {
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
         int nt_i, mt_i;
         if (p.m_fast) {
             mt_i = w % p.mt;
@@ -623,7 +625,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     {
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
         int nt_i, mt_i;
         if (p.m_fast) {
             mt_i = w % p.mt;
@@ -1100,7 +1103,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     {
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
         int nt_i, mt_i;
         if (p.m_fast) {
             mt_i = w % p.mt;
@@ -1141,7 +1145,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ring2_kernel(const ConvK p)
     {
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
         int nt_i, mt_i;
         if (p.m_fast) {
             mt_i = w % p.mt;
@@ -1469,7 +1474,8 @@ __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
     {   // XCD-aware mapping, clips fastest: the workgroups of one (channel tile, split) share the weight stream
         const int nwg = p.nt * p.mt * p.splits;
         const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
-        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
         clip = w % p.mt;
         const int rest = w / p.mt;
         n0 = (rest % p.nt) * G::BN;
@@ -1907,6 +1913,7 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     k.steps_per_split = (k.nsteps + d->splits - 1) / d->splits;
     k.k_total = d->kh * d->kw * k.c_pad + k.c_pad2;
     k.slab_rows = d->slab_rows;
+    k.reverse = cp360_launch_reverse();
     k.clip_rows = 6 * d->h_out * d->w_out;
     k.nsub = k.k_total / (bk / 2);
     k.sub_per_split = (k.nsub + d->splits - 1) / d->splits;

@@ -335,4 +335,18 @@ extern "C" const char* cp360_strerror(int status) {
 }
 
 extern "C" int cp360_version(void) { return CP360_VERSION; }
+
+static thread_local int t_launch_mode = 0;      // 0 ascending, 1 descending, 2 alternate
+static thread_local int t_launch_flip = 0;
+int cp360_launch_reverse() {
+    if (t_launch_mode != 2) return t_launch_mode;
+    t_launch_flip ^= 1;
+    return t_launch_flip;
+}
+extern "C" int cp360_set_launch_order(int mode) {
+    const int old = t_launch_mode;
+    t_launch_mode = (mode == 1 || mode == 2) ? mode : 0;
+    t_launch_flip = 0;
+    return old;
+}
 extern "C" size_t cp360_conv_desc_bytes(void) { return sizeof(cp360_conv_desc); }

@@ -145,14 +145,15 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
                                                          const T* __restrict__ xds, const T* __restrict__ wdf,
                                                          T* __restrict__ out, const T* __restrict__ w1f,
-                                                         const float* __restrict__ bias1, T* __restrict__ out_next) {
+                                                         const float* __restrict__ bias1, T* __restrict__ out_next,
+                                                         int reverse) {
     typedef L1Geom<NV, BANDV> G;
     constexpr int N = G::N, NP = G::NP, BAND = G::BAND, WPR = G::WPR, PATCH_PX = G::PATCH_PX, PATCH_INST = G::PATCH_INST;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds_base = (unsigned)(size_t)lds;
-    const int tile = blockIdx.x, img = tile / (N / BAND), band = tile - img * (N / BAND);
+    const int tile = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x, img = tile / (N / BAND), band = tile - img * (N / BAND);
     const int grp = img / 6, f = img - grp * 6;
     const CubePadGeom geom{N, 1, 1, 1, 1};
     const int lrow = lane & 15, lchunk = lane >> 4;
@@ -462,7 +463,7 @@ extern "C" int cp360_l1block_forward(int dtype, const void* mid, const void* w2_
 #define CP360_L1B(TT, DSV, NX, NV, BV)                                                                          \
     hipLaunchKernelGGL((l1block_kernel<TT, DSV, NX, NV, BV>), dim3((unsigned)(n_img * (NV / BV))), dim3(256), 0, st, \
                        (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, \
-                       (const TT*)x_ds, (const TT*)wd_frags, (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next)
+                       (const TT*)x_ds, (const TT*)wd_frags, (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next, cp360_launch_reverse())
 #define CP360_L1B_F(TT, NV, BV)                                 \
     {                                                           \
         if (x_ds && w1_frags) CP360_L1B(TT, true, true, NV, BV);  \

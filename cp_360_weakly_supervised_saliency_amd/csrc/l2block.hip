@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
                                                          T* __restrict__ out, const T* __restrict__ w1f,
-                                                         const float* __restrict__ bias1, T* __restrict__ out_next) {
+                                                         const float* __restrict__ bias1, T* __restrict__ out_next,
+                                                         int reverse) {
     typedef BtGeom<CV, NV, BANDV, NB> G;
     constexpr int C = G::C, CO = G::CO, N = G::N, NP = G::NP, BAND = G::BAND, PXV = G::PXV, PB = G::PB,
                   PATCH_INST = G::PATCH_INST, PATCH_LDS = G::PATCH_LDS, T_STRIDE = G::T_STRIDE, PXB = G::PXB, RBW = G::RBW,
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half_wg = wave >> 2, w4 = wave & 3;              // band A / B of this workgroup, wave inside the band
     const unsigned lds_base = (unsigned)(size_t)lds;
-    const int gband = blockIdx.x * NB + half_wg;                // global band = img * 7 + band
+    const int gband = (reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * NB + half_wg;   // global band = img * 7 + band (descending: cp360_set_launch_order)
     const int img = gband / (N / BAND), band = gband - img * (N / BAND);
     const int grp = img / 6, f = img - grp * 6;
     const CubePadGeom geom{N, 1, 1, 1, 1};
@@ -508,7 +509,7 @@ static int bt_launch(int layer, int dtype, const void* mid, const void* w2_packe
 #define CP360_L2B(TT, CV, NBV, NV, BV, NX)                                                                           \
     hipLaunchKernelGGL((l2block_kernel<TT, CV, NBV, NV, BV, NX>), dim3((unsigned)(n_img * (NV / BV) / NBV)), dim3(256 * NBV), 0, st, \
                        (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, (TT*)out, \
-                       (const TT*)w1_frags, bias1, (TT*)out_next)
+                       (const TT*)w1_frags, bias1, (TT*)out_next, cp360_launch_reverse())
 #define CP360_L2B_T(TT)                                                  \
     {                                                                    \
         if (layer == 3) CP360_L2B(TT, 256, 1, 14, 7, false);             \

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void cubepad_maxpool_kernel(const T* __restric
 typedef __attribute__((ext_vector_type(4))) unsigned int mp_u32x4;
 template <typename T>
 __global__ __launch_bounds__(256) void cubepad_maxpool16_kernel(const T* __restrict__ x, T* __restrict__ y, int n6, int n,
-                                                                int C, int ho) {
+                                                                int C, int ho, int reverse) {
     const CubePadGeom g{n, 1, 1, 1, 1};
     const int cv = C / 8;
     const long long total = (long long)n6 * ho * ho * cv;
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void cubepad_maxpool16_kernel(const T* __restr
     const long long chunk = (total + 7) / 8;
     const long long lo = (blockIdx.x & 7) * chunk, hi = min(total, lo + chunk);
     const long long stride = (long long)(gridDim.x >> 3) * blockDim.x;
-    for (long long idx = lo + (long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; idx < hi; idx += stride) {
+    for (long long i0 = lo + (long long)(blockIdx.x >> 3) * blockDim.x + threadIdx.x; i0 < hi; i0 += stride) {
+        const long long idx = reverse ? total - 1 - i0 : i0;       // descending order (cp360_set_launch_order)
         const int c = (int)(idx % cv) * 8;
         long long t = idx / cv;
         const int ox = (int)(t % ho);
@@ -109,10 +110,10 @@ extern "C" int cp360_cubepad_maxpool3s2(const void* x, void* y, int n6, int n, i
                            (const float*)x, (float*)y, n6, n, C, ho);
     else if (dtype == CP360_BF16 && C % 8 == 0)
         hipLaunchKernelGGL((cubepad_maxpool16_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const bf16_raw*)x, (bf16_raw*)y, n6, n, C, ho);
+                           (const bf16_raw*)x, (bf16_raw*)y, n6, n, C, ho, cp360_launch_reverse());
     else if (dtype == CP360_F16 && C % 8 == 0)
         hipLaunchKernelGGL((cubepad_maxpool16_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st,
-                           (const f16_raw*)x, (f16_raw*)y, n6, n, C, ho);
+                           (const f16_raw*)x, (f16_raw*)y, n6, n, C, ho, cp360_launch_reverse());
     else if (dtype == CP360_BF16)
         hipLaunchKernelGGL((cubepad_maxpool_kernel<bf16_raw, 4>), dim3((unsigned)blocks), dim3(256), 0, st,
                            (const bf16_raw*)x, (bf16_raw*)y, n6, n, C, ho);

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict_
 template <typename T, int CDV>
 __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, const T* __restrict__ wpk,
                                                       const float* __restrict__ bias, T* __restrict__ out, int n_img,
-                                                      int relu) {
+                                                      int relu, int reverse) {
     typedef StemGeom<CDV> G;
     constexpr int WP = G::WP, WO = G::WO, ROW_BYTES = G::ROW_BYTES, BAND = G::BAND, PATCH_BYTES = G::PATCH_BYTES,
                   PATCH_LDS = G::PATCH_LDS, PATCH_INST = G::PATCH_INST, MJ = G::MJ, WPR = G::WPR;
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
     // patch of tile t -> buffer b: PATCH_INST DMA instructions of 1 KiB, wave w issues w, w+8, ...; the bytes
     // past the patch's end come from a zero line (never read by the MFMAs)
     auto load_patch = [&](int t, int b) __attribute__((always_inline)) {
+        if (reverse) t = ntiles - 1 - t;                       // descending tile order (cp360_set_launch_order)
         const int img = t / (WO / BAND), band = t - img * (WO / BAND);
         const unsigned char* src0 = xb + (size_t)img * img_bytes + (size_t)(2 * BAND * band) * ROW_BYTES;
 #pragma unroll
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
                 for (int j = 0; j < MJ; ++j) mma<T>(acc[i][j], a[i], b[j]);
         }
         // epilogue: output row (band*8 + wave) of image img
-        const int img = t / (WO / BAND), band = t - img * (WO / BAND);
+        const int tt = reverse ? ntiles - 1 - t : t;
+        const int img = tt / (WO / BAND), band = tt - img * (WO / BAND);
         T* orow = out + (((size_t)img * WO + band * BAND + wrow) * WO + col0) * 64;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
@@ -232,7 +234,7 @@ extern "C" int cp360_stem_forward(int dtype, const void* xp, const void* packed,
         const int ntiles = n_img * (StemGeom<CDV>::WO / StemGeom<CDV>::BAND);                                   \
         const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));                                               \
         hipLaunchKernelGGL((stem_kernel<TT, CDV>), grid, dim3(512), 0, st, (const TT*)xp, (const TT*)packed, bias, \
-                           (TT*)out, n_img, relu);                                                              \
+                           (TT*)out, n_img, relu, cp360_launch_reverse());                                      \
     }
     if (dtype == CP360_BF16) { if (cube_dim == 224) CP360_STEM(bf16_raw, 224) else CP360_STEM(bf16_raw, 512) }
     else if (dtype == CP360_F16) { if (cube_dim == 224) CP360_STEM(f16_raw, 224) else CP360_STEM(f16_raw, 512) }

@@ -14,6 +14,8 @@ physical NHWC) so hooks and callers see the reference's shapes.
 
 Inference only (the north star is the inference path): no autograd through the HIP ops.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -28,6 +30,7 @@ FUSE_DOWNSAMPLE = True
 FUSE_LAYER1 = True
 FUSE_LAYER2 = True
 FUSE_LAYER3 = True
+LAUNCH_ORDER = int(os.environ.get('CP360_LAUNCH_ORDER', '2'))   # 0: every launch ascending (A/B switch)
 FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
 
 
@@ -284,12 +287,15 @@ class ResNet(nn.Module):
 
     def features_nhwc(self, x_nhwc4, padded=False):
         """Fused path to layer4: [6N, H, W, 4] -> [6N, H/32, W/32, 2048]."""
-        x = self.stem_nhwc(x_nhwc4, padded)
-        x = self.layer1_nhwc(x)
-        x = self.layer2_nhwc(x)
-        x = self.layer3_nhwc(x)
-        for blk in self.layer4:
-            x = blk.forward_nhwc(x)
+        # every launch walks its work items against the order of the launch before it: the consumer starts with the
+        # lines its producer wrote last, still in the 256 MB Infinity Cache (ops.launch_order, tools/mall_probe.hip)
+        with ops.launch_order(LAUNCH_ORDER):
+            x = self.stem_nhwc(x_nhwc4, padded)
+            x = self.layer1_nhwc(x)
+            x = self.layer2_nhwc(x)
+            x = self.layer3_nhwc(x)
+            for blk in self.layer4:
+                x = blk.forward_nhwc(x)
         return x
 
     def forward(self, x):

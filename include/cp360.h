@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 209
+#define CP360_VERSION 210
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -321,6 +321,16 @@ int cp360_l3block_pack_weights(int dtype, const float* w_oihw, const float* scal
 int cp360_l3block_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2,
                           const void* w3_frags, const float* bias3, const void* residual, void* out,
                           int n_img, int face, void* stream);
+
+/* ------------------------------------------------------------------ launch order (a performance hint)
+ * Work-item order of the launches the CALLING THREAD issues from now on: 0 = ascending (default), 1 = descending,
+ * 2 = alternating, starting with descending (convolutions, stem, max-pool, Bottleneck tail kernels; the others ignore
+ * it and do not count).  Results never depend on it.  Why: the
+ * 256 MB Infinity Cache keeps what a kernel wrote LAST; a consumer that walks its input in the producer's order starts
+ * with the lines that were evicted first and, for tensors above 256 MB, misses all the way (tools/mall_probe.hip: a
+ * 308 MB buffer read back front-to-back 3.8 TB/s, back-to-front 6.3 TB/s).  Alternating the order between a producer
+ * and its consumer lets the consumer begin with the resident lines.  Returns the previous setting. */
+int cp360_set_launch_order(int mode);
 
 /* ------------------------------------------------------------------ K3b: max-pool
  * CubePad(1) + MaxPool2d(3, stride 2, padding 0) (resnet_cubic.py:128,169-170),
