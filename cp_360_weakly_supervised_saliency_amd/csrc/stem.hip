@@ -206,6 +206,258 @@ __global__ __launch_bounds__(512, 2) void stem_kernel(const T* __restrict__ xp, 
     }
 }
 
+// ------------------------------------------------------------------ stem + CubePad(1) + max-pool 3x3 s2 in one kernel
+// (resnet_cubic.py:165-170; cube 224, 16-bit types, ReLU on).  Separately the stem writes its 112x112x64 output
+// (616 MB for 64 frames) and the max-pool reads it again; here the pooled 56x56x64 map (154 MB) is all that leaves.
+//   * a workgroup owns a band of 8 stem rows = 4 pooled rows; pooled row 4b needs stem row 8b-1 as well: that halo
+//     row is computed again (9 rows x 7 pixel blocks = 63 units: wave w takes its row's 7 blocks and block w of the
+//     halo row), its 23 padded input rows are one contiguous 42 KB range (double-buffered LDS-DMA as above);
+//   * a wave pools its own row HORIZONTALLY in registers: after bias + ReLU + rounding a lane holds 8 channels of one
+//     pixel as four dwords of two 16-bit values; the left / right neighbour pixels are the neighbouring lanes of
+//     its 16-lane row (DPP row_shr / row_shl; lane 0's left neighbour is lane 15 of the previous block: row_ror of
+//     that block's register), and the maximum of non-negative bf16 / fp16 values is the maximum of their bit patterns
+//     (v_pk_max_u16); even pixels keep the result and store it to LDS (8 rows x 56 x 128 B), the halo row goes there raw;
+//   * after a barrier the vertical 3-maximum runs from LDS and the pooled rows leave with 16-byte stores.
+// CubePad(1) of the max-pool needs stem pixels of OTHER faces (row -1 / column -1 of the padded map): this kernel
+// treats them as absent, also writes the four border rows / columns of every face's stem output to `border`
+// ([n_img][top, bottom, left, right][112][64], 57 KB per face) and stem_pool_fix_kernel folds the padding in
+// afterwards (pooled row 0 and column 0 of every face: 111 of 3136 pixels).  Bit-identical to the two-kernel path.
+namespace {
+constexpr int SP_PATCH_ROWS = 23, SP_PATCH_BYTES = SP_PATCH_ROWS * 1840, SP_PATCH_INST = 42, SP_PATCH_LDS = SP_PATCH_INST * 1024;
+constexpr int SP_HROW = 56 * 128;                           // one horizontally pooled row
+constexpr int SP_EXTRA = 2 * SP_HROW + 112 * 128;           // pooled rows 6, 7 and the raw halo row (28,672 B)
+static_assert(6 * SP_HROW == SP_PATCH_LDS, "pooled rows 0-5 take the place of the current patch");
+__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ u32x4 pkmax4(const u32x4& a, const u32x4& b) {
+    return u32x4{pkmax(a.x, b.x), pkmax(a.y, b.y), pkmax(a.z, b.z), pkmax(a.w, b.w)};
+}
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(512) void stem_pool_kernel(const T* __restrict__ xp, const T* __restrict__ wpk,
+                                                       const float* __restrict__ bias, T* __restrict__ y,
+                                                       T* __restrict__ border, int n_img, int reverse) {
+    constexpr int WP = 230, WO = 112, HO = 56, ROW_BYTES = 1840, BAND = 8, NBAND = WO / BAND;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[W_BYTES + 2 * SP_PATCH_LDS + SP_EXTRA];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int ntiles = n_img * NBAND;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xp);
+    const size_t img_bytes = (size_t)WP * ROW_BYTES;
+    unsigned char* extra = lds + W_BYTES + 2 * SP_PATCH_LDS;
+
+    // patch of tile t -> buffer b: padded input rows 16 band - 2 .. 16 band + 20 (band 0 has no halo row: its first two
+    // patch rows are never read and come from the zero line)
+    auto load_patch = [&](int t, int b) __attribute__((always_inline)) {
+        if (reverse) t = ntiles - 1 - t;
+        const int img = t / NBAND, band = t - img * NBAND;
+        const long long row0 = (long long)16 * band - 2;
+        const unsigned char* src0 = xb + (size_t)img * img_bytes + row0 * ROW_BYTES;
+#pragma unroll
+        for (int q = 0; q < (SP_PATCH_INST + 7) / 8; ++q) {
+            const int inst = wave + 8 * q;
+            if (inst < SP_PATCH_INST) {
+                const int off = inst * 1024 + lane * 16;
+                const bool ok = off < SP_PATCH_BYTES && (band > 0 || off >= 2 * ROW_BYTES);
+                const void* src = ok ? (const void*)(src0 + off) : (const void*)s_zero16;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_base + W_BYTES + b * SP_PATCH_LDS + inst * 1024));
+            }
+        }
+    };
+    {   // weights: as stem_kernel
+        const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int inst = wave + 8 * q;
+            if (inst < 28) {
+                const int row = inst * 16 + (lane >> 2);
+                const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
+                glds16(wb + row * 64 + chunk * 16, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+            }
+        }
+    }
+    int t = blockIdx.x;
+    if (t < ntiles) load_patch(t, 0);
+
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // the patch landed; the other buffer and `extra` are free
+        if (t + (int)gridDim.x < ntiles) load_patch(t + gridDim.x, buf ^ 1);
+        const int tt = reverse ? ntiles - 1 - t : t;
+        const int img = tt / NBAND, band = tt - img * NBAND;
+        const bool halo = band > 0 && wave < 7;                    // unit 7: block `wave` of stem row 8 band - 1
+        unsigned char* pbuf = lds + W_BYTES + buf * SP_PATCH_LDS;
+
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[i][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // stem row 8 band + w = patch rows 2 (w + 1) ..; the halo row = patch rows 0 ..
+        const unsigned char* P = pbuf + (2 * (wave + 1)) * ROW_BYTES + 16 * (lrow + lchunk);
+        const unsigned char* PH = pbuf + 16 * (wave * 16 + lrow + lchunk);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            u32x4 a[4], b[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(lds + w_swz(ky * 64 + i * 16 + lrow, lchunk));
+#pragma unroll
+            for (int u = 0; u < 7; ++u) b[u] = *reinterpret_cast<const u32x4*>(P + ky * ROW_BYTES + u * 256);
+            b[7] = *reinterpret_cast<const u32x4*>(PH + ky * ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mma<T>(acc[i][u], a[i], b[u]);
+        }
+        __syncthreads();                                           // every wave is done reading the patch
+        // ---- bias + ReLU + one rounding; border copies; horizontal 3-maximum; pooled rows / halo row -> LDS
+        const int srow = band * BAND + wave;                       // this wave's stem row
+        T* bimg = border + (size_t)img * 4 * WO * 64;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n = pr * 32 + lchunk * 8;
+            float bl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bl[e] = bias ? bias[n + e] : 0.f;
+            u32x4 o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[2 * pr][u][e] + bl[e], 0.f);
+                    v[4 + e] = fmaxf(acc[2 * pr + 1][u][e] + bl[4 + e], 0.f);
+                }
+                o[u] = pack8(v, T());
+            }
+            // the face's border rows / columns, raw (the max-pool's CubePad reads them from other faces)
+            if (srow == 0 || srow == WO - 1) {
+                T* brow = bimg + (size_t)(srow == 0 ? 0 : 1) * WO * 64;
+#pragma unroll
+                for (int u = 0; u < 7; ++u) *reinterpret_cast<u32x4*>(brow + (size_t)(u * 16 + lrow) * 64 + n) = o[u];
+            }
+            if (lrow == 0) *reinterpret_cast<u32x4*>(bimg + ((size_t)2 * WO + srow) * 64 + n) = o[0];
+            if (lrow == 15) *reinterpret_cast<u32x4*>(bimg + ((size_t)3 * WO + srow) * 64 + n) = o[6];
+            // horizontal 3-maximum at the even pixels: x = 16 u + lrow, neighbours x - 1 / x + 1 (x = 0: no left one)
+            unsigned char* hrow = wave < 6 ? pbuf + wave * SP_HROW : extra + (wave - 6) * SP_HROW;
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                u32x4 m = o[u];
+                const unsigned* cur = reinterpret_cast<const unsigned*>(&o[u]);
+                const unsigned* prv = reinterpret_cast<const unsigned*>(&o[u > 0 ? u - 1 : 0]);
+                unsigned* mm = reinterpret_cast<unsigned*>(&m);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned right = (unsigned)__builtin_amdgcn_update_dpp(0, (int)cur[d], 0x101, 0xf, 0xf, true);     // row_shl:1
+                    // lane 0 of the 16-lane row: lane 15 of the previous block (row_ror:1 of its register); block 0: nothing
+                    const unsigned wrap = u > 0 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)prv[d], 0x121, 0xf, 0xf, true) : 0u;
+                    const unsigned left = (unsigned)__builtin_amdgcn_update_dpp((int)wrap, (int)cur[d], 0x111, 0xf, 0xf, false);   // row_shr:1
+                    mm[d] = pkmax(pkmax(cur[d], left), right);
+                }
+                if ((lrow & 1) == 0)
+                    *reinterpret_cast<u32x4*>(hrow + (u * 8 + (lrow >> 1)) * 128 + n * 2) = m;
+            }
+            if (halo) *reinterpret_cast<u32x4*>(extra + 2 * SP_HROW + (wave * 16 + lrow) * 128 + n * 2) = o[7];
+        }
+        __syncthreads();                                           // the pooled rows (and the halo row) are complete
+        // ---- vertical 3-maximum: pooled row i of the band = stem rows 2i-1 (i = 0: the halo row), 2i, 2i+1
+        T* yimg = y + ((size_t)img * HO + band * 4) * HO * 64;
+        for (int it = tid; it < 4 * HO * 8; it += 512) {
+            const int i = it / (HO * 8), rem = it - i * (HO * 8);
+            const int c = rem >> 3, k = rem & 7;
+            auto hp = [&](int r) __attribute__((always_inline)) -> u32x4 {
+                const unsigned char* base = r < 6 ? pbuf + r * SP_HROW : extra + (r - 6) * SP_HROW;
+                return *reinterpret_cast<const u32x4*>(base + c * 128 + k * 16);
+            };
+            u32x4 m = pkmax4(hp(2 * i), hp(2 * i + 1));
+            if (i > 0) {
+                m = pkmax4(m, hp(2 * i - 1));
+            } else if (band > 0) {
+                const unsigned char* hr = extra + 2 * SP_HROW + k * 16;
+                m = pkmax4(m, *reinterpret_cast<const u32x4*>(hr + (2 * c) * 128));
+                m = pkmax4(m, *reinterpret_cast<const u32x4*>(hr + (2 * c + 1) * 128));
+                if (c > 0) m = pkmax4(m, *reinterpret_cast<const u32x4*>(hr + (2 * c - 1) * 128));
+            }
+            *reinterpret_cast<u32x4*>(yimg + ((size_t)i * HO + c) * 64 + k * 8) = m;
+        }
+    }
+}
+
+// CubePad(1) of the max-pool: pooled row 0 and column 0 of every face take the maximum with the padding pixels of their
+// windows - padded row -1 / column -1 of the face = border pixels of other faces' stem outputs (cubepad_src).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pool_fix_kernel(T* __restrict__ y, const T* __restrict__ border, int n_img) {
+    constexpr int WO = 112, HO = 56;
+    const CubePadGeom g{WO, 1, 1, 1, 1};
+    const int total = n_img * (2 * HO - 1) * 8;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int k = idx & 7;
+        int rest = idx >> 3;
+        const int e = rest % (2 * HO - 1);                         // 0..55: pooled (0, e); 56..110: pooled (e - 55, 0)
+        const int img = rest / (2 * HO - 1);
+        const int grp = img / 6, f = img - grp * 6;
+        const int oy = e < HO ? 0 : e - (HO - 1), ox = e < HO ? e : 0;
+        T* py = y + (((size_t)img * HO + oy) * HO + ox) * 64 + k * 8;
+        u32x4 m = *reinterpret_cast<const u32x4*>(py);
+        auto pad = [&](int pyy, int pxx) __attribute__((always_inline)) {           // padded coordinates, row or column 0
+            const int s = cubepad_src(f, pyy, pxx, g);             // pixel of the group's 6 x 112 x 112 stem output
+            const int sf = s / (WO * WO), r = s - sf * (WO * WO);
+            const int sy = r / WO, sx = r - sy * WO;
+            const int side = sy == 0 ? 0 : sy == WO - 1 ? 1 : sx == 0 ? 2 : 3;
+            const int pos = side < 2 ? sx : sy;
+            const T* src = border + ((((size_t)grp * 6 + sf) * 4 + side) * WO + pos) * 64 + k * 8;
+            m = pkmax4(m, *reinterpret_cast<const u32x4*>(src));
+        };
+        // the window of pooled (oy, ox) covers padded rows 2 oy .. 2 oy + 2, columns 2 ox .. 2 ox + 2
+        if (oy == 0) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) pad(0, 2 * ox + kx);
+        }
+        if (ox == 0) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                if (oy > 0 || ky > 0) pad(2 * oy + ky, 0);
+        }
+        *reinterpret_cast<u32x4*>(py) = m;
+    }
+}
+
+extern "C" size_t cp360_stem_pool_border_bytes(int n_img) { return n_img > 0 ? (size_t)n_img * 4 * 112 * 64 * 2 : 0; }
+
+extern "C" int cp360_stem_pool_forward(int dtype, const void* xp, const void* packed, const float* bias, void* y,
+                                       void* border, int n_img, int cube_dim, void* stream) {
+    if (!xp || !packed || !y || !border) return CP360_ERR_NULL;
+    if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
+    if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+    if (cube_dim != 224) return CP360_ERR_UNSUPPORTED;             // other cube sizes: cp360_stem_forward + cp360_cubepad_maxpool3s2
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = n_img * 14;
+    const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
+    const int rev = cp360_launch_reverse();
+    const int fix_blocks = (n_img * 111 * 8 + 255) / 256;
+#define CP360_SP(TT)                                                                                                   \
+    {                                                                                                                  \
+        hipLaunchKernelGGL((stem_pool_kernel<TT>), grid, dim3(512), 0, st, (const TT*)xp, (const TT*)packed, bias, (TT*)y, \
+                           (TT*)border, n_img, rev);                                                                   \
+        hipLaunchKernelGGL((stem_pool_fix_kernel<TT>), dim3((unsigned)fix_blocks), dim3(256), 0, st, (TT*)y,            \
+                           (const TT*)border, n_img);                                                                  \
+    }
+    if (dtype == CP360_BF16) CP360_SP(bf16_raw)
+    else if (dtype == CP360_F16) CP360_SP(f16_raw)
+#undef CP360_SP
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
 extern "C" size_t cp360_stem_packed_bytes(int dtype) {
     return (dtype == CP360_BF16 || dtype == CP360_F16) ? (size_t)W_BYTES : 0;
 }

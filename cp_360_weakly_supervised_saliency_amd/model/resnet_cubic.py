@@ -30,6 +30,7 @@ FUSE_DOWNSAMPLE = True
 FUSE_LAYER1 = True
 FUSE_LAYER2 = True
 FUSE_LAYER3 = True
+FUSE_STEM_POOL = os.environ.get('CP360_FUSE_STEM_POOL', '1') != '0'    # A/B switch: 0 = stem kernel, then max-pool kernel
 LAUNCH_ORDER = int(os.environ.get('CP360_LAUNCH_ORDER', '2'))   # 0: every launch ascending (A/B switch)
 FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
 
@@ -196,8 +197,12 @@ class ResNet(nn.Module):
         CubePad(3) -> conv7x7 s2 + BN + ReLU -> CubePad(1) + maxpool (resnet_cubic.py:165-170).
         padded=True: x is already the CubePad(3) output [6N, H+6, W+6, 4] (Equi2Cube layout 'nhwc4p3')."""
         xp = x_nhwc4 if padded else ops.cubepad_nhwc(x_nhwc4, 3)
-        x = self._stem_conv()(xp)
-        return ops.cubepad_maxpool3s2(x)
+        conv = self._stem_conv()
+        if FUSE_STEM_POOL:
+            y = conv.stem_pool(xp)               # one kernel at cube 224 / 16-bit (csrc/stem.hip, stem_pool_kernel)
+            if y is not None:
+                return y
+        return ops.cubepad_maxpool3s2(conv(xp))
 
     def _layer1_fused(self):
         """ops.L1Block per Bottleneck of layer1 (K3d), rebuilt when a parameter changes."""

@@ -305,6 +305,27 @@ class Conv:
                                    cd, int(self.relu), stream()))
         return out
 
+    def stem_pool(self, xp):
+        """cp360_stem_pool_forward: stem + CubePad(1) + max-pool 3x3 s2 in one kernel (cube 224, 16-bit types, ReLU):
+        xp [n_img, 230, 230, 4] -> [n_img, 56, 56, 64]; None when this convolution / input is not that case."""
+        if not (self.stem and self.relu and self.dtype in (torch.bfloat16, torch.float16) and xp.dtype == self.dtype
+                and tuple(xp.shape[1:]) == (230, 230, 4) and xp.shape[0] % 6 == 0):
+            return None
+        require_gpu(xp)
+        L = lib()
+        code = dtype_code(self.dtype)
+        if self._stem_packed is None:
+            w = self._w_src.to(device=self.device, dtype=torch.float32).contiguous()
+            t = torch.empty(L.cp360_stem_packed_bytes(code), dtype=torch.uint8, device=self.device)
+            check(L.cp360_stem_pack_weights(code, ptr(w), ptr(self._scale), ptr(t), stream()))
+            self._stem_packed = t
+        n_img = xp.shape[0]
+        y = torch.empty((n_img, 56, 56, 64), dtype=self.dtype, device=xp.device)
+        border = torch.empty(L.cp360_stem_pool_border_bytes(n_img), dtype=torch.uint8, device=xp.device)
+        check(L.cp360_stem_pool_forward(code, ptr(xp.contiguous()), ptr(self._stem_packed), ptr(self.bias), ptr(y),
+                                        ptr(border), n_img, 224, stream()))
+        return y
+
     def _band_resident(self, x):
         """cp360_band3x3_forward: layer1 conv2 with the band's padded pixels resident in LDS (K3c)."""
         L = lib()

@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 210
+#define CP360_VERSION 211
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -247,6 +247,15 @@ int cp360_stem_pack_weights(int dtype, const float* w_oihw /* [64,3,7,7] */, con
                             void* packed, void* stream);
 int cp360_stem_forward(int dtype, const void* xp, const void* packed, const float* bias, void* out,
                        int n_img, int cube_dim, int relu, void* stream);
+/* The stem AND the max-pool behind it (CubePad(1) + MaxPool2d(3, 2), resnet_cubic.py:169-170) in one kernel: cube size
+ * 224, CP360_BF16 / CP360_F16, ReLU on (csrc/stem.hip, stem_pool_kernel): xp as above -> y [n_img, 56, 56, 64]; the
+ * 112x112x64 stem output is never written.  `border`: scratch of cp360_stem_pool_border_bytes(n_img) bytes (the four
+ * border rows / columns of every face's stem output, from which a second small launch folds the max-pool's cube padding
+ * into pooled row 0 / column 0).  Bit-identical to cp360_stem_forward + cp360_cubepad_maxpool3s2.  Other cube sizes:
+ * CP360_ERR_UNSUPPORTED. */
+size_t cp360_stem_pool_border_bytes(int n_img);
+int cp360_stem_pool_forward(int dtype, const void* xp, const void* packed, const float* bias, void* y, void* border,
+                            int n_img, int cube_dim, void* stream);
 
 /* ------------------------------------------------------------------ K3c: resident-band 3x3
  * CubePad(1) + conv 3x3 stride 1 (64 -> 64) + folded BatchNorm + ReLU = conv2 / bn2 / relu of layer1's

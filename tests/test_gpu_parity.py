@@ -529,6 +529,35 @@ def test_stem_resident_patch_kernel_cube224(prec):
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('order', [0, 1])
+def test_stem_pool_fused_kernel_bit_exact(prec, order):
+    """csrc/stem.hip stem_pool_kernel (+ stem_pool_fix_kernel): stem conv + BN + ReLU -> CubePad(1) -> max-pool 3x3 s2 in
+    one kernel at cube 224 must equal the two-kernel path (resident stem, then cubepad_maxpool3s2) bit for bit - the
+    same MFMA order per output and maxima of identical values; 12 faces (every band of a face in its own workgroup) and
+    300 faces (4200 band tiles on 256 persistent workgroups: the double-buffered loop, several cubes), both launch orders."""
+    dt = _TDT[prec]
+    w = hashrng.normal(9641, (64, 3, 7, 7), 0, (2.0 / (49 * 64)) ** 0.5)
+    scale = hashrng.uniform(9642, (64,), 0.5, 1.5)
+    bias = hashrng.normal(9643, (64,), 0, 0.1)
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 2, 0, True, dt, DEV, stem=True)
+    for n_img, seed in ((12, 9640), (300, 9650)):
+        x = hashrng.normal(seed, (12, 3, 224, 224))
+        x3 = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV))
+        x4 = ops.cubepad_nhwc(x3, 0, c_out=4)
+        x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)
+        if n_img > 12:                                              # more cubes: the same two, rolled and sign-flipped
+            reps = [torch.roll(x4, k, dims=1 + k % 2) * (1.0 if k % 3 else -1.0) for k in range(n_img // 12)]
+            x4 = torch.cat(reps, 0).contiguous()
+        xp = ops.cubepad_nhwc(x4, 3)
+        want = ops.cubepad_maxpool3s2(conv(xp))
+        with ops.launch_order(order):
+            got = conv.stem_pool(xp)
+        assert got is not None and got.shape == want.shape == (n_img, 56, 56, 64)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), \
+            int((got.view(torch.int16) != want.view(torch.int16)).sum())
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 def test_band3x3_resident_kernel_layer1_conv2(prec):
     """K3c: CubePad(1) + 3x3 conv 64 -> 64 + BN + ReLU on 56x56 faces (12 faces = two cubes: the halo of
     every band comes through cubepad_src from the other faces of ITS cube) against torch-CPU on the same
