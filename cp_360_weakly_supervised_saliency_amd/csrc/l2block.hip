@@ -7,8 +7,9 @@
 // layer2 geometry; layer3's differences are listed at BtGeom.  Separately these are a
 // generic implicit GEMM that re-gathers its im2col rows once per tap (conv2, 0.15 ms per block for 64 frames) and
 // an HBM-bound 1x1 (conv3, 0.15 ms) with t making a round trip through HBM in between.  Here, as in l1block.hip:
-//   * a workgroup (8 waves) owns TWO bands of 4 output rows (112 pixels = 7 MFMA pixel blocks each, no padding
-//     columns: a band's pixels are consecutive in memory); waves 0-3 work on band A, waves 4-7 on band B;
+//   * a workgroup of 4 waves owns a band of 4 output rows (112 pixels = 7 MFMA pixel blocks, no padding columns: a
+//     band's pixels are consecutive in memory), two workgroups per CU (NB = 2 - one workgroup of 8 waves with two
+//     bands - exists as an A/B variant and measured slower);
 //   * stage 1 (conv2): each band's 6 x 30 cube-padded pixels (256 B each, 45 KB) are gathered ONCE by LDS-DMA through
 //     cubepad_src(); the nine taps read them there (the 16-byte chunk c of patch pixel (row, col) sits at chunk
 //     c ^ ((row * N + col) & 15): the 16 pixels of an MFMA block are consecutive OUTPUT pixels, so this key runs through
@@ -20,8 +21,11 @@
 //     K reduction of conv3 needs all four waves' channels - where the band's patch was;
 //   * stage 3 (conv3): wave w computes the 32-channel pairs w&3, +4, +8, +12 of the 512 outputs (K = 128: 56 MFMAs
 //     per pass), A fragments from L2 (fragment order, prefetched one pass ahead), adds the residual piece (16-byte
-//     loads prefetched one pass ahead), ReLU, one rounding, 16-byte stores.
+//     loads prefetched one pass ahead), ReLU, one rounding, 16-byte stores;
+//   * NEXT (layer2, 28x28 faces): the next identity block's conv1 (512 -> 128) from the output pieces, through an LDS
+//     slice per pass (see the NEXT branch).
 // HBM traffic per block (64 frames): mid 77 MB + residual 308 MB + out 308 MB; t (77 MB x 2) never leaves the CU.
+// Work-item order: cp360_set_launch_order (descending band order when `reverse`).
 #include "common.h"
 #include <stdlib.h>
 
