@@ -100,3 +100,24 @@ def test_stem_and_resize_entry_points_validate_without_gpu():
     assert L.cp360_resize_ksize(3840, 1920) == 13 and L.cp360_resize_ksize(100, 200) == 7
     assert L.cp360_resize_ksize(0, 5) == -1
     assert L.cp360_resize_lanczos_u8(None, one, None, 1, 4, 4, 2, 2, None, None, 0, None, None, 0, None) == -5
+
+
+def test_round2_entry_points_validate_without_gpu():
+    """The fused kernels added in round 2: sizes and argument checks (no launch on the CPU box); the launch-order hint
+    is host state and returns the previous mode."""
+    import ctypes as C
+    L = _lib.lib()
+    one = C.c_void_p(16)
+    assert L.cp360_l2block_packed_bytes(_lib.F16) == 9 * 128 * 128 * 2 and L.cp360_l3block_packed_bytes(_lib.BF16) == 9 * 256 * 256 * 2
+    assert L.cp360_l2block_packed_bytes(_lib.F32) == 0
+    assert L.cp360_l2block_forward(_lib.F16, one, one, None, one, one, one, one, 6, 14, None) == -8      # layer2: faces 28 / 64
+    assert L.cp360_l3block_forward(_lib.F16, one, one, None, one, one, one, one, 6, 28, None) == -8      # layer3: faces 14
+    assert L.cp360_l3block_forward(_lib.F16, one, one, None, one, one, one, one, 5, 14, None) == -2      # not 6N
+    assert L.cp360_l2block_forward_next(_lib.F16, one, one, None, one, one, one, one, one, None, one, 6, 64, None) == -8   # chained conv1: 28x28 only
+    assert L.cp360_l2block_forward_next(_lib.F16, one, one, None, one, one, one, one, None, None, one, 6, 28, None) == -5
+    assert L.cp360_stem_pool_border_bytes(6) == 6 * 4 * 112 * 64 * 2 and L.cp360_stem_pool_border_bytes(0) == 0
+    assert L.cp360_stem_pool_forward(_lib.BF16, one, one, None, one, one, 6, 512, None) == -8            # cube 224 only
+    assert L.cp360_stem_pool_forward(_lib.BF16, one, one, None, one, None, 6, 224, None) == -5
+    assert L.cp360_stem_pool_forward(_lib.F32, one, one, None, one, one, 6, 224, None) != 0
+    old = L.cp360_set_launch_order(2)
+    assert L.cp360_set_launch_order(1) == 2 and L.cp360_set_launch_order(7) == 1 and L.cp360_set_launch_order(old) == 0
