@@ -105,6 +105,10 @@ for v in variants:
     if v == 'slab_bf16emu':
         sub('store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);',
             '{ for (int e_ = 0; e_ < 4; ++e_) v[e_] = __uint_as_float(((unsigned)f32_to_bf16(v[e_])) << 16); store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v); }')
+    if v == 'clip_noslab':     # ablation: the split-K slab stores of the clip kernel never execute (accumulators stay live)
+        i = s.index('constexpr int CLIP_JH = 0;')
+        j = s.rindex('store4(p.partial + ((size_t)split * p.M + m) * p.c_out + (p.slab_rows ? slab_col(n) : n), v);', 0, i)
+        s = s[:j] + 'if (v[0] == 1.2345e-30f) ' + s[j:]
     if v.startswith('clip_jh'):   # clip kernel: MFMA columns issued in the load half (0 = pure load / compute halves)
         sub('constexpr int CLIP_JH = 0;', 'constexpr int CLIP_JH = %d;' % int(v[7:]))
     if v == 'clip_nw7':        # clip kernel: seven weight stages
