@@ -267,6 +267,29 @@ def test_resnet_fused_downsample_equals_separate(golden_dir):
     assert rel_err(outs[0], outs[1]) <= 2e-5
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'fp16'])
+def test_launch_order_never_changes_results(prec):
+    """cp360_set_launch_order is a traversal hint: the whole static stage (every kernel that honours it: stem + pool,
+    generic / ring convolutions, layer1-3 tails) gives the same bits ascending, descending and alternating."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    dt = _TDT[prec]
+    m, _ = _load_resnet(prec)
+    x = torch.from_numpy(hashrng.normal(4100, (12, 224, 224, 3), 0.0, 1.0)).to(DEV)
+    x4 = ops.cubepad_nhwc(x, 0, c_out=4)
+    if dt != torch.float32:
+        x4 = ops.nchw_to_nhwc(x4.reshape(1, 1, 1, -1), out_dtype=dt).reshape(x4.shape)
+    outs = []
+    old = rc.LAUNCH_ORDER
+    try:
+        for mode in (0, 1, 2):
+            rc.LAUNCH_ORDER = mode
+            outs.append(m.features_nhwc(x4).clone())
+    finally:
+        rc.LAUNCH_ORDER = old
+    assert outs[0].shape == (12, 7, 7, 2048)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 def test_layer1_fused_block_kernel_cube512_faces(prec):
     """K3d at 128x128 faces (cube 512, BASELINE config C5): two output rows per workgroup, two waves per row."""
