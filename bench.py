@@ -180,7 +180,7 @@ def cpu_baseline(precision, dev, static_precision=None):
     both maps against fixations sampled from the oracle map, and CC(build, oracle): reported under "check"."""
     from tests.parity_helpers import oracle_pipeline, oracle_cam_frames
     from oracle import o_metrics
-    # 32 threads: fastest setting measured on the GPU box's host (tools/cpu_threads_probe.py); using all
+    # 32 threads: fastest setting measured on the GPU box's host (tests/probe_cpu_threads.py); using all
     # 256 hardware threads of the EPYC host makes oneDNN ~100x slower on these small convolutions
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     rs = synth.resnet50_state(seed=1)

@@ -36,7 +36,7 @@ class SaliencyEngine:
         # ``static_precision`` that of the static stage (cube projection output, ResNet-50, CAM conv).  The
         # stages meet at the f32 CAM scores.  A bf16 engine runs the static stage in fp16 by default: same
         # MFMA rate and bytes, 3 more mantissa bits - measured on a 1024x2048 T=16 clip against the oracle
-        # (tools/exp_precision_split.py): bf16 ResNet -> map max|d| 3.4e-3, dCC 1.2e-3 whatever the ConvLSTM
+        # (tests/probe_precision_split.py): bf16 ResNet -> map max|d| 3.4e-3, dCC 1.2e-3 whatever the ConvLSTM
         # runs in; fp16 ResNet + bf16 ConvLSTM -> 5.2e-4, dCC 2.2e-4.
         self.precision = precision
         self.static_precision = static_precision or ('fp16' if precision == 'bf16' else precision)

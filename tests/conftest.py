@@ -12,7 +12,7 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     # the oracle is torch-CPU: on the GPU box's 256-thread host oneDNN is ~100x slower with all threads
-    # than with 32 (tools/cpu_threads_probe.py)
+    # than with 32 (tests/probe_cpu_threads.py)
     try:
         import torch
         torch.set_num_threads(min(32, os.cpu_count() or 1))

@@ -8,7 +8,7 @@ cube 224), HIP path vs the oracle:
       every clip against the oracle run on that clip alone.
 
 "bf16" is the engine's default 16-bit mode: ConvLSTM (81 % of the flops) in bf16, static stage in fp16 (same
-MFMA rate; a bf16 ResNet alone moves the map by 3.4e-3 and CC by 1.2e-3, tools/exp_precision_split.py).
+MFMA rate; a bf16 ResNet alone moves the map by 3.4e-3 and CC by 1.2e-3, tests/probe_precision_split.py).
 The all-bf16 engine (static_precision='bf16') is run too, against the looser bound it actually meets.
 
 The 16-bit gate follows SURVEY 8(d): AUC-Judd and CC of the build's map against a fixation map
