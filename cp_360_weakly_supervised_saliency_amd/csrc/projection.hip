@@ -101,21 +101,23 @@ __global__ __launch_bounds__(256) void equi2cube_kernel(const TI* __restrict__ e
                 sh0[u] = (unsigned)(ad0 & 3) * 8;
                 sh1[u] = (unsigned)(ad1 & 3) * 8;
             }
-            auto funnel = [](const uint3& d, unsigned sh) {
-                const unsigned long long lo = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
-                return sh ? (lo >> sh) | ((unsigned long long)d.z << (64 - sh)) : lo;
+            // the 6 bytes of a row's two taps start sh / 8 bytes into the 12 loaded ones: two v_alignbyte_b32 bring them
+            // to dwords (bytes 0-3, bytes 4-7), six v_cvt_f32_ubyteN turn them into floats (no 64-bit shifts)
+            auto taps = [](const uint3& d, unsigned sh, float lo3[3], float hi3[3]) {
+                const unsigned sb = sh >> 3;
+                const unsigned wa = __builtin_amdgcn_alignbyte(d.y, d.x, sb), wb = __builtin_amdgcn_alignbyte(d.z, d.y, sb);
+                lo3[0] = (float)(wa & 0xffu); lo3[1] = (float)((wa >> 8) & 0xffu); lo3[2] = (float)((wa >> 16) & 0xffu);
+                hi3[0] = (float)(wa >> 24); hi3[1] = (float)(wb & 0xffu); hi3[2] = (float)((wb >> 8) & 0xffu);
             };
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 if (fr0 + u >= F) break;
-                const unsigned long long q0 = funnel(d0[u], sh0[u]), q1 = funnel(d1[u], sh1[u]);
+                float t00[3], t01[3], t10[3], t11[3];
+                taps(d0[u], sh0[u], t00, t01);
+                taps(d1[u], sh1[u], t10, t11);
                 float v[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float t00 = (float)((q0 >> (8 * c)) & 0xff), t01 = (float)((q0 >> (8 * (c + 3))) & 0xff);
-                    const float t10 = (float)((q1 >> (8 * c)) & 0xff), t11 = (float)((q1 >> (8 * (c + 3))) & 0xff);
-                    v[c] = (t00 * w00 + t01 * w01 + t10 * w10 + t11 * w11) * scale;
-                }
+                for (int c = 0; c < 3; ++c) v[c] = (t00[c] * w00 + t01[c] * w01 + t10[c] * w10 + t11[c] * w11) * scale;
                 emit(fr0 + u, v);
             }
         } else {
