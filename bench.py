@@ -78,8 +78,9 @@ def cpu_model():
     return 'unknown'
 
 
-def timed(step, warmup, steps, dev):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+def timed(step, warmup, steps, dev, per_rank=False):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
+    per_rank: also this rank's own time up to its synchronize, BEFORE the closing barrier (diagnosis of N > 1 runs)."""
     out = None
     for _ in range(warmup):
         out = step()
@@ -90,9 +91,11 @@ def timed(step, warmup, steps, dev):
     for _ in range(steps):
         out = step()
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
     cpdist.barrier()
     torch.cuda.synchronize()
-    return cpdist.max_over_ranks(time.perf_counter() - t0, dev), out
+    total = cpdist.max_over_ranks(time.perf_counter() - t0, dev)
+    return ((total, mine) if per_rank else total), out
 
 
 def roofline_pass(eng, frames, precision, steps=2):
@@ -113,8 +116,12 @@ def roofline_pass(eng, frames, precision, steps=2):
     ms /= n
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = None, None
-    tp = os.path.join(REPO, 'profiles', 'traffic_%s.json' % precision)
-    if os.path.exists(tp) and (eng.B, eng.w) == (4, 7):          # counters were collected on this launch shape only
+    # PMC counters cannot be read inside the run: the per-launch HBM bytes come from the tracked rocprofv3 summary of
+    # the SAME launch shape (precision, clips per GPU, face size), when one has been collected
+    tp = os.path.join(REPO, 'profiles', 'traffic_%s_b%d_w%d.json' % (precision, eng.B, eng.w))
+    if not os.path.exists(tp) and (precision, eng.B, eng.w) == ('bf16', 4, 7):
+        tp = os.path.join(REPO, 'profiles', 'traffic_bf16.json')
+    if os.path.exists(tp):
         t = json.load(open(tp))
         traffic, src = t.get('conv_igemm_clstm_bytes_per_launch'), 'profiles/' + t.get('source', '')
     M = 6 * eng.B * eng.w * eng.w
@@ -126,15 +133,21 @@ def roofline_pass(eng, frames, precision, steps=2):
 
 
 def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, graph=False, static_only=False,
-                 frame_chunk=None, source_hw=None, want_roofline=False, static_precision=None):
+                 frame_chunk=None, source_hw=None, want_roofline=False, static_precision=None, all_steps=False,
+                 f32_input=False):
     rs = synth.resnet50_state(seed=1)
     cs = synth.clstm_state(seed=2)
     eng = SaliencyEngine(rs, cs, (H, W), cd, clips=B, frames=T, precision=precision, device=dev,
-                         frame_chunk=frame_chunk, source_hw=source_hw, static_precision=static_precision)
+                         frame_chunk=frame_chunk, source_hw=source_hw, static_precision=static_precision,
+                         return_all_steps=all_steps)
     del rs, cs
     fh, fw = source_hw if source_hw else (H, W)
     # this rank's clips (global clip id = rank*B + b), resident in HBM before timing
     frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + rank * B + b, T, fh, fw)) for b in range(B)]).to(dev)
+    if f32_input:
+        # SURVEY 8(d), "uint8 and fp32 variants": the reference feeds np.array(img) / 255.0 (dataset_feat_extractor.py:142);
+        # here as f32 [H, W, 3] in [0, 1] resident in HBM (4x the input bytes of the u8 variant, K1 scale 1.0)
+        frames = frames.to(torch.float32) / 255.0
     n_clips = world * B
     if graph and not static_only:
         eng.capture(frames)
@@ -147,29 +160,111 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
         sal = eng(frames)
         return cpdist.gather_maps(sal, n_clips, rank, world)
 
-    elapsed, out = timed(step, warmup, steps, dev)
+    elapsed, out = timed(step, warmup, steps, dev, per_rank=True)
+    elapsed, mine = elapsed
     assert (static_only or out.shape[0] == n_clips) and bool(torch.isfinite(out).all())
     res = {'value': round(world * B * T * steps / elapsed, 3), 'ms_per_step': round(1000.0 * elapsed / steps, 3),
            'roofline': None}
+    # diagnosis of the N > 1 runs (never part of `value`): every rank's own ms per step and the all-gather alone
+    res['ms_per_step_per_rank'] = [round(1000.0 * v / steps, 3) for v in cpdist.all_ranks(mine, dev)]
+    if not static_only:
+        sal = eng(frames)
+        torch.cuda.synchronize()
+        cpdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            cpdist.gather_maps(sal, n_clips, rank, world)
+        torch.cuda.synchronize()
+        res['allgather_ms'] = round(cpdist.max_over_ranks(time.perf_counter() - t0, dev) * 100.0, 4)
+        res['allgather_bytes_per_rank'] = int(sal.numel() * sal.element_size())
+        res['map_shape'] = list(out.shape)
     if want_roofline and not static_only:
         if graph:
             eng._graph = None                      # the roofline pass needs eager launches to bracket
         res['roofline'] = roofline_pass(eng, frames, precision)
     res['w'] = eng.w
     res['static_dtype'] = DTYPE[eng.static_precision]
+    res['fp16_fallback'] = bool(eng.fp16_fallback)      # fp16 static stage overflowed on the first batch -> bf16 (pipeline.py)
     del eng, frames
     torch.cuda.empty_cache()
     return res
 
 
-def workload_name(static_only, B, T, H, W, cd, w, src_hw=None):
+def workload_name(static_only, B, T, H, W, cd, w, src_hw=None, all_steps=False, f32_input=False):
+    inp = 'f32 [0,1]' if f32_input else 'u8'
     if static_only:
-        return 'C2 static path only: %d x %d frames %dx%d u8 equi -> 6x%d^2 cube -> CubePad ResNet-50 -> CAM' % (B, T, H, W, cd)
-    s = ('%d clips x %d frames %dx%d u8 equi -> 6x%d^2 cube -> CubePad ResNet-50 -> CAM -> ConvLSTM x%d -> '
-         'cube_to_equi saliency %dx%d' % (B, T, H, W, cd, T, 2 * w, 4 * w))
+        return 'C2 static path only: %d x %d frames %dx%d %s equi -> 6x%d^2 cube -> CubePad ResNet-50 -> CAM' % (B, T, H, W, inp, cd)
+    s = ('%d clips x %d frames %dx%d %s equi -> 6x%d^2 cube -> CubePad ResNet-50 -> CAM -> ConvLSTM x%d -> '
+         'cube_to_equi saliency %dx%d' % (B, T, H, W, inp, cd, T, 2 * w, 4 * w))
+    if all_steps:
+        s += ' after EVERY step (return_all_steps: [clips, %d, %d, %d] gathered)' % (T, 2 * w, 4 * w)
     if src_hw:
         s += ' (frames decoded at %dx%d, PIL-exact Lanczos resize included)' % src_hw
     return s
+
+
+def level1_bench(dev, precision='fp32', reps=5):
+    """The drop-in (module-boundary) path timed as the reference's drivers use it - numpy in, numpy out, one call per
+    frame / per ConvLSTM step, H2D + D2H copies and the per-call layout conversions included (never the headline):
+      static   dataset_feat_extractor.py:145-162: to_cube(img) dict -> im_norm -> concatenate -> CAM(...) per frame
+      temporal test_temporal.py:63-85: window min/max, 5 x ``hidden, cell = model(frame, [hidden, cell])``,
+               ``c2e.to_equi_nn`` + ``torch.max`` -> one map per window (seq_len 5, config.yaml:34)."""
+    from cp_360_weakly_supervised_saliency_amd.model.clstm import ConvLSTMCell
+    from cp_360_weakly_supervised_saliency_amd.model.resnet_cubic import resnet50
+    from cp_360_weakly_supervised_saliency_amd.static_model.class_activation_model import CAM
+    from cp_360_weakly_supervised_saliency_amd.utils.cube_to_equi import Cube2Equi
+    from cp_360_weakly_supervised_saliency_amd.utils.equi_to_cube import Equi2Cube
+    from cp_360_weakly_supervised_saliency_amd.utils.utils import im_norm
+    H, W, cd, T = 1024, 2048, 224, 5
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=2)
+    model = resnet50(precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}, strict=False)
+    model = model.to(dev).eval()
+    cell = ConvLSTMCell(1000, 1000, precision=precision)
+    cell.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in cs.items()})
+    cell = cell.to(dev).eval()
+    del rs, cs
+    frame = synth.frame_u8(31, H, W)
+    input_img = np.array(frame) / 255.0
+    e2c = Equi2Cube(cd, input_img, device=dev)
+
+    def static_frame():
+        cubes = e2c.to_cube(input_img)
+        batch = np.concatenate([np.expand_dims(im_norm(cubes[i], [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]), 0)
+                                for i in range(6)], axis=0).astype(np.float32)
+        return CAM(batch, None, model, 'layer4', 'fc.weight', use_gpu=True)[0]
+
+    c2e = Cube2Equi(7, device=dev)
+    subseq = [f for f in synth.cam_clip(6005, T)]
+
+    def temporal_window():
+        mx, mn = np.max(subseq), np.min(subseq)
+        init = (subseq[0] - mn) / (mx - mn)
+        cst = torch.FloatTensor(init).to(dev)
+        hidden = torch.FloatTensor(init).to(dev)
+        for f in subseq:
+            f = torch.FloatTensor((f - mn) / (mx - mn)).to(dev)
+            hidden, cst = cell(f, [hidden, cst])
+        return torch.squeeze(torch.max(c2e.to_equi_nn(hidden), 1)[0]).cpu().numpy()
+
+    def rate(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    ts, tw = rate(static_frame), rate(temporal_window)
+    del model, cell
+    torch.cuda.empty_cache()
+    return {'name': 'Level-1 drop-in path (reference driver loops on the shims, numpy in / numpy out, %s)' % precision,
+            'static_frames_per_s': round(1.0 / ts, 2), 'static_ms_per_frame': round(1000 * ts, 2),
+            'temporal_maps_per_s': round(1.0 / tw, 2), 'temporal_ms_per_window': round(1000 * tw, 2),
+            'window': 'seq_len 5 (config.yaml:34): 5 ConvLSTMCell calls + to_equi_nn + max',
+            'what': 'to_cube dict -> im_norm -> CAM() per 1024x2048 frame; 5 x model(frame, [hidden, cell]) + '
+                    'to_equi_nn + torch.max per window; PCIe copies and NCHW<->NHWC conversions of every call included'}
 
 
 def cpu_baseline(precision, dev, static_precision=None):
@@ -264,6 +359,9 @@ def main():
     ap.add_argument('--frame-chunk', type=int, default=0, help='frames per static-stage group (0 = all)')
     ap.add_argument('--graph', action='store_true', help='replay the step from a HIP graph (launch-bound small configs)')
     ap.add_argument('--source', default='', help='decoded frame size HxW: include the PIL-exact Lanczos resize (K0) in the step')
+    ap.add_argument('--all-steps', action='store_true',
+                    help='return_all_steps: one map per ConvLSTM step, [clips, T, 2w, 4w] gathered instead of [clips, 2w, 4w]')
+    ap.add_argument('--f32-input', action='store_true', help='frames resident as f32 [H, W, 3] in [0, 1] instead of u8 (SURVEY 8(d))')
     ap.add_argument('--static-only', action='store_true',
                     help='BASELINE config C2: the static path only (equi -> cube -> ResNet-50 -> CAM); no roofline object')
     ap.add_argument('--cpu-anchor', action='store_true',
@@ -287,7 +385,8 @@ def main():
 
     head = run_workload(dev, rank, world, H, W, args.cube, B, T, args.precision, args.steps, args.warmup,
                         graph=args.graph, static_only=args.static_only, frame_chunk=args.frame_chunk or None,
-                        source_hw=src_hw, want_roofline=(rank == 0), static_precision=args.static_precision or None)
+                        source_hw=src_hw, want_roofline=(rank == 0), static_precision=args.static_precision or None,
+                        all_steps=args.all_steps, f32_input=args.f32_input)
 
     if rank == 0:
         line = {
@@ -295,22 +394,35 @@ def main():
             'value': head['value'], 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': DTYPE[args.precision], 'data': 'synthetic',
+            # the arithmetic type(s) the path computes in: temporal stage (ConvLSTM, 81 % of the flops) + static stage
+            # (ResNet-50 / CAM) when they differ - the default 16-bit engine is bf16 + f16
+            'dtype': DTYPE[args.precision] if head['static_dtype'] == DTYPE[args.precision]
+                     else '%s+%s' % (DTYPE[args.precision], head['static_dtype']),
+            'mixed_precision': head['static_dtype'] != DTYPE[args.precision],
+            'data': 'synthetic',
             'config': {'workload': ('' if args.static_only else 'C3/C4 per-GPU shard: ')
-                                   + workload_name(args.static_only, B, T, H, W, args.cube, head['w'], src_hw),
+                                   + workload_name(args.static_only, B, T, H, W, args.cube, head['w'], src_hw,
+                                                   args.all_steps, args.f32_input),
                        'clips_per_gpu': B, 'frames_per_clip': T, 'equi': [H, W], 'cube_dim': args.cube,
                        'graph_replay': bool(args.graph),
                        'temporal_stage_dtype': DTYPE[args.precision], 'static_stage_dtype': head['static_dtype'],
+                       'static_stage_fp16_fallback': head['fp16_fallback'],
                        'parallelism': 'clips sharded over %d GPU(s), 1 all-gather of maps' % world},
             'roofline': head['roofline'],
             'cpu_baseline': None,
+            # diagnosis of multi-GPU runs (not part of `value`): each rank's own ms per step before the closing barrier,
+            # and the single collective of the path - the all-gather of the maps - timed alone after the timed region
+            'ms_per_step_per_rank': head.get('ms_per_step_per_rank'),
+            'allgather_ms': head.get('allgather_ms'), 'allgather_bytes_per_rank': head.get('allgather_bytes_per_rank'),
+            'map_shape': head.get('map_shape'),
         }
         if world == 1 and not args.no_secondary:
             sec = []
 
             def add(name, H2, W2, cd2, B2, T2, prec, steps, warmup, **kw):
                 r = run_workload(dev, 0, 1, H2, W2, cd2, B2, T2, prec, steps, warmup, want_roofline=not kw.get('static_only'), **kw)
-                sec.append({'name': name, 'workload': workload_name(kw.get('static_only', False), B2, T2, H2, W2, cd2, r['w']),
+                sec.append({'name': name, 'workload': workload_name(kw.get('static_only', False), B2, T2, H2, W2, cd2, r['w'],
+                                                                    None, kw.get('all_steps', False), kw.get('f32_input', False)),
                             'dtype': DTYPE[prec], 'static_stage_dtype': r['static_dtype'], 'graph_replay': bool(kw.get('graph')), 'value': r['value'],
                             'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': steps, 'warmup': warmup,
                             'roofline': r['roofline']})
@@ -322,6 +434,11 @@ def main():
             add('C3 literal: one 16-frame clip, bf16, hipGraph replay', 1024, 2048, 224, 1, 16, 'bf16', 10, 3, graph=True)
             add('C2: one frame (6 faces), fp32, static path only', 1024, 2048, 224, 1, 1, 'fp32', 20, 5, static_only=True)
             add('C5 per-GPU shard: one 16-frame 2048x4096 clip, 6x512^2 faces, fp16', 2048, 4096, 512, 1, 16, 'fp16', 3, 1)
+            add('C4 per-GPU shard, frames resident as f32 [0,1] instead of u8 (SURVEY 8(d) fp32-input variant)',
+                1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
+            add('C4 per-GPU shard, return_all_steps: a map after every ConvLSTM step ([4, 16, 14, 28])',
+                1024, 2048, 224, 4, 16, args.precision, 5, 2, all_steps=True)
+            sec.append(level1_bench(dev))
             line['secondary'] = sec
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.precision, dev, args.static_precision or None)

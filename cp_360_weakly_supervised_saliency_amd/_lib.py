@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 211
+ABI_VERSION = 300
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -37,7 +37,7 @@ SYMBOLS = [
     'cp360_conv_finish',
     'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_lstm_gates_next', 'cp360_window_minmax',
     'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes', 'cp360_band3x3_pack_weights', 'cp360_band3x3_forward',
-    'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1', 'cp360_l1block_forward', 'cp360_l1block_conv2_bytes',
+    'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1', 'cp360_l1block_forward', 'cp360_l1block_forward_wide', 'cp360_l1block_conv2_bytes',
     'cp360_l1block_pack_conv2',
     'cp360_l2block_packed_bytes', 'cp360_l2block_pack_weights', 'cp360_l2block_forward', 'cp360_l2block_forward_next', 'cp360_set_launch_order', 'cp360_stem_pool_border_bytes', 'cp360_stem_pool_forward',
     'cp360_l3block_packed_bytes', 'cp360_l3block_pack_weights', 'cp360_l3block_forward',
@@ -118,6 +118,7 @@ def lib():
     L.cp360_frag_packed_bytes.argtypes = [i, i, i]
     L.cp360_frag_pack_1x1.argtypes = [i, vp, vp, vp, i, i, i, vp]
     L.cp360_l1block_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.cp360_l1block_forward_wide.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.cp360_l2block_packed_bytes.restype = sz
     L.cp360_l2block_packed_bytes.argtypes = [i]
     L.cp360_l2block_pack_weights.argtypes = [i, vp, vp, vp, vp]

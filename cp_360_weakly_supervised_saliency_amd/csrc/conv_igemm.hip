@@ -1967,10 +1967,14 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
             const char* e = getenv("CP360_RING");           // A/B switch for tools/bench_conv.py
             return e ? atoi(e) : 1;
         }();
+        // the DMA kernels have no second-source loader (their K loop would run the extra tap on the first tensor):
+        // a second-source descriptor always takes a ring kernel, whatever CP360_RING says
+        const bool ring = use_ring || d->c_in2 > 0;
+        if (d->c_in2 > 0 && !big && bm_ != 129) return CP360_ERR_UNSUPPORTED;
 #define CP360_WIDE(TT)                                                                                     \
         {                                                                                                      \
             if (bm == 304) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 304>), grid, dim3(512), 0, st, k);   \
-            else if (big && use_ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 256>), grid, dim3(512), 0, st, k); \
+            else if (big && ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 256>), grid, dim3(512), 0, st, k); \
             else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 8>), grid, dim3(512), 0, st, k);       \
             else          hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 4>), grid, dim3(512), 0, st, k);       \
         }

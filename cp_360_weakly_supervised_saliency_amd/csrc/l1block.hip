@@ -22,6 +22,11 @@
 // then), the downsample filter's fragments come from L2.  Wave w = output row w of the band, as in stage 1.
 // HBM traffic per block (64 frames): mid 154 MB + residual 616 MB + out 616 MB (+ mid' 154 MB) instead of
 // 154 + 154 | 154 + 616 + 616 | 616 + 154.
+// NEXTC = 128 (round 3): the LAST block of layer1 chains layer2's first conv1 (1x1, 256 -> 128, model/resnet_cubic.py:
+// 88-90 of layer2.0), whose own launch re-read the 616 MB this kernel has just written.  128 accumulator channels do not
+// fit next to the tail's registers for 64 pixels per wave, so stage 3 runs twice over HALF of the wave's pixel blocks
+// (2 x 8 passes; conv3's fragments - 4 KiB per pass - then come from L2 one pass ahead instead of from LDS, which holds
+// the 64 KiB of next-conv1 fragments).
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -35,6 +40,9 @@ constexpr int W2_TAP = 8 * 1024;                             // conv2: 8 fragmen
 constexpr int W3_BYTES = CO * C * 2;                         // 32 KiB of conv3 fragments
 constexpr int W1_BYTES = C * CO * 2;                         // 32 KiB of next-conv1 fragments
 constexpr int STAGE3_LDS = W3_BYTES + W1_BYTES + (CO + C) * 4;
+constexpr int C1W = 128;                                     // the wide chained conv1 (layer2.0's: 256 -> 128)
+constexpr int W1W_BYTES = C1W * CO * 2;                      // 64 KiB of its fragments
+constexpr int STAGE3W_LDS = W1W_BYTES + (CO + C1W) * 4;
 // Face size N, BAND output rows per workgroup (4 waves): 56x56 faces (cube 224) -> 4 rows, wave = row (64 pixel slots,
 // 8 of them padding); 128x128 faces (cube 512, BASELINE config C5) -> 2 rows, two waves per row (64 pixels each).
 template <int N_, int BAND_> struct L1Geom {
@@ -43,8 +51,9 @@ template <int N_, int BAND_> struct L1Geom {
     static constexpr int PATCH_INST = (PATCH_PX + 7) / 8;                     // DMA instructions of 8 pixels x 128 B
     static constexpr int PATCH_LDS = PATCH_INST * 1024;                       // 45,056 / 66,560
     static constexpr int READ_END = ((BAND + 1) * NP + 2 + 64 * WPR) * 128;   // padding columns read past the patch
-    static constexpr int LDS_BYTES = (PATCH_LDS > READ_END ? PATCH_LDS : READ_END) > STAGE3_LDS
-                                         ? (PATCH_LDS > READ_END ? PATCH_LDS : READ_END) : STAGE3_LDS;   // 66,816: two per CU
+    static constexpr int STAGE1_LDS = PATCH_LDS > READ_END ? PATCH_LDS : READ_END;
+    static constexpr int LDS_BYTES = STAGE1_LDS > STAGE3_LDS ? STAGE1_LDS : STAGE3_LDS;                // 66,816: two per CU
+    static constexpr int LDS_BYTES_W = STAGE1_LDS > STAGE3W_LDS ? STAGE1_LDS : STAGE3W_LDS;            // 67,072 (NEXTC = 128)
     static_assert(N % BAND == 0 && 64 * WPR >= N && 4 % BAND == 0, "band geometry");
 };
 
@@ -408,6 +417,230 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     }
 }
 
+// The last block of layer1 (identity residual) with the WIDE chained conv1 (256 -> 128 = layer2.0's conv1): stages 1-2
+// as l1block_kernel; stage 3 twice over half of the wave's pixel blocks (see the header).
+template <typename T, int NV, int BANDV>
+__global__ __launch_bounds__(256, 2) void l1block_wide_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
+                                                              const float* __restrict__ bias2, const T* __restrict__ w3f,
+                                                              const float* __restrict__ bias3, const T* __restrict__ res,
+                                                              T* __restrict__ out, const T* __restrict__ w1f,
+                                                              const float* __restrict__ bias1, T* __restrict__ out_next,
+                                                              int reverse) {
+    typedef L1Geom<NV, BANDV> G;
+    constexpr int N = G::N, NP = G::NP, BAND = G::BAND, WPR = G::WPR, PATCH_PX = G::PATCH_PX, PATCH_INST = G::PATCH_INST;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES_W];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int tile = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x, img = tile / (N / BAND), band = tile - img * (N / BAND);
+    const int grp = img / 6, f = img - grp * 6;
+    const CubePadGeom geom{N, 1, 1, 1, 1};
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    const int wrow = wave / WPR, x0 = (wave - wrow * WPR) * 64;
+    const size_t row_px = ((size_t)img * N + band * BAND + wrow) * N + x0;
+
+    // ---- stage 1 (as l1block_kernel)
+    {
+        const T* xg = x + (size_t)grp * 6 * N * N * C;
+#pragma unroll 1
+        for (int inst = wave; inst < PATCH_INST; inst += 4) {
+            const int q = inst * 8 + (lane >> 3);
+            const void* src = l_zero16;
+            if (q < PATCH_PX) {
+                const int pr = q / NP, pc = q - pr * NP;
+                const int sp = cubepad_src(f, BAND * band + pr, pc, geom);
+                src = xg + (size_t)sp * C + (((lane & 7) ^ px_swz(q)) << 3);
+            }
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+        }
+    }
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk2);
+    auto load_a = [&](int t, u32x4 (&a)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                a[i][kk] = *reinterpret_cast<const u32x4*>(wb + (size_t)t * W2_TAP + ((i * 2 + kk) * 64 + lane) * 16);
+    };
+    constexpr int DEPTH = 2;
+    u32x4 bt[2][4];
+    {
+        u32x4 aq[DEPTH + 1][4][2];
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) load_a(t, aq[t]);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + DEPTH < 9) load_a(tap + DEPTH, aq[(tap + DEPTH) % (DEPTH + 1)]);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int pbase = (wrow + ky) * NP + kx + x0 + lrow;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int p = pbase + 16 * j;
+                    b[j] = *reinterpret_cast<const u32x4*>(lds + p * 128 + (((kk * 4 + lchunk) ^ px_swz(p)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], aq[tap % (DEPTH + 1)][i][kk], b[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // every wave is done with the patch: bring the chained conv1's fragments in (64 KiB)
+        __syncthreads();
+        {
+            const unsigned char* s1 = reinterpret_cast<const unsigned char*>(w1f);
+#pragma unroll
+            for (int q = 0; q < W1W_BYTES / 1024 / 4; ++q) {
+                const int inst = q * 4 + wave;
+                glds16(s1 + inst * 1024 + lane * 16, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+            }
+        }
+        // ---- stage 2: t = relu(conv2 + b2), rounded once, as B fragments bt[k-block][pixel block]
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n = pr * 32 + lchunk * 8;
+            float bb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = bias2 ? bias2[n + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[2 * pr][j][e] + bb[e], 0.f);
+                    v[4 + e] = fmaxf(acc[2 * pr + 1][j][e] + bb[4 + e], 0.f);
+                }
+                bt[pr][j] = pack8(v, T());
+            }
+        }
+    }
+    float* bias_s = reinterpret_cast<float*>(lds + W1W_BYTES);
+    bias_s[tid] = bias3[tid];
+    if (tid < C1W) bias_s[CO + tid] = bias1 ? bias1[tid] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the fragment DMAs
+    __syncthreads();
+
+    // ---- stage 3, per half h of the wave's pixel blocks (j = 2h, 2h + 1): conv3 in 8 passes of 32 channels + residual
+    // -> out, and the chained conv1's 128 channels accumulated on the fly (8 row blocks x 2 pixel blocks)
+    const unsigned char* W1s = lds;
+    const unsigned char* w3g = reinterpret_cast<const unsigned char*>(w3f);
+    auto load_w3 = [&](int p, u32x4 (&a)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                a[rb][kb] = *reinterpret_cast<const u32x4*>(w3g + (((p * 2 + rb) * 2 + kb) * 64 + lane) * 16);
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        auto load_res = [&](int p, u32x4 (&r)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * h + jj;
+                const int xo = x0 + j * 16 + lrow;
+                const T* src = xo < N ? res + (row_px + j * 16 + lrow) * CO + p * 32 + lchunk * 8 : reinterpret_cast<const T*>(l_zero16);
+                r[jj] = *reinterpret_cast<const u32x4*>(src);
+            }
+        };
+        f32x4 acc[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 r[2], r1[2], a3[2][2];
+        load_res(0, r);
+        load_res(1, r1);
+        load_w3(0, a3);
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+            u32x4 r2[2], a3n[2][2];
+            if (p < 6) load_res(p + 2, r2);
+            if (p < 7) load_w3(p + 1, a3n);
+            const int n = p * 32 + lchunk * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + n), b1v = *reinterpret_cast<const f32x4*>(bias_s + n + 4);
+            f32x4 c3[2][2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) c3[rb][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) mma<T>(c3[rb][jj], a3[rb][kb], bt[kb][2 * h + jj]);
+            u32x4 o[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * h + jj;
+                float v[8], rv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = c3[0][jj][e] + b0[e];
+                    v[4 + e] = c3[1][jj][e] + b1v[e];
+                }
+                unpack8(r[jj], rv, T());
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] + rv[e], 0.f);
+                o[jj] = pack8(v, T());
+                const int xo = x0 + j * 16 + lrow;
+                if (xo < N) *reinterpret_cast<u32x4*>(out + (row_px + j * 16 + lrow) * CO + n) = o[jj];
+            }
+            // out's channels 32p .. 32p+31 = k-block p of the chained conv1 (fragment order 1: (kb * 8 + rb))
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                u32x4 a1[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    a1[rb] = *reinterpret_cast<const u32x4*>(W1s + ((p * 8 + half * 4 + rb) * 64 + lane) * 16);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) mma<T>(acc[half * 4 + rb][jj], a1[rb], o[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                r[jj] = r1[jj];
+                r1[jj] = r2[jj];
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) a3[rb][kb] = a3n[rb][kb];
+        }
+        T* orow = out_next + row_px * C1W;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const int n = pr * 32 + lchunk * 8;
+            float bb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = bias_s[CO + n + e];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * h + jj;
+                const int xo = x0 + j * 16 + lrow;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[2 * pr][jj][e] + bb[e], 0.f);
+                    v[4 + e] = fmaxf(acc[2 * pr + 1][jj][e] + bb[4 + e], 0.f);
+                }
+                if (xo < N) *reinterpret_cast<u32x4*>(orow + (size_t)(j * 16 + lrow) * C1W + n) = pack8(v, T());
+            }
+        }
+    }
+}
+
 extern "C" size_t cp360_frag_packed_bytes(int dtype, int n_out, int k) {
     if ((dtype != CP360_BF16 && dtype != CP360_F16) || n_out <= 0 || k <= 0 || n_out % 32 != 0 || k % 32 != 0) return 0;
     return (size_t)n_out * k * 2;
@@ -443,6 +676,30 @@ extern "C" int cp360_l1block_pack_conv2(int dtype, const float* w_oihw, const fl
         hipLaunchKernelGGL((l1_pack_conv2_kernel<f16_raw>), dim3(blocks), dim3(256), 0, st, w_oihw, scale, (f16_raw*)packed);
     else
         return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_l1block_forward_wide(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                                          const void* w3_frags, const float* bias3, const void* residual, void* out,
+                                          const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
+                                          void* stream) {
+    if (!mid || !w2_packed || !w3_frags || !bias3 || !out || !residual || !w1_frags || !out_next) return CP360_ERR_NULL;
+    if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
+    if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+    if (face != 56 && face != 128) return CP360_ERR_UNSUPPORTED;
+    if ((long long)n_img * face * face * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define CP360_L1W(TT, NV, BV)                                                                                       \
+    hipLaunchKernelGGL((l1block_wide_kernel<TT, NV, BV>), dim3((unsigned)(n_img * (NV / BV))), dim3(256), 0, st,      \
+                       (const TT*)mid, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)residual, \
+                       (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next, cp360_launch_reverse())
+#define CP360_L1W_T(TT) { if (face == 56) CP360_L1W(TT, 56, 4); else CP360_L1W(TT, 128, 2); }
+    if (dtype == CP360_BF16) CP360_L1W_T(bf16_raw)
+    else if (dtype == CP360_F16) CP360_L1W_T(f16_raw)
+    else return CP360_ERR_BAD_DTYPE;
+#undef CP360_L1W_T
+#undef CP360_L1W
     CP360_CHECK_HIP();
     return CP360_OK;
 }

@@ -142,8 +142,8 @@ template <typename TI, typename TO>
 static int launch_e2c(const void* equi, const float* grid, void* out, int F, int H, int W, int cd, const float* mean,
                       const float* istd, float scale, int layout, int fixed, hipStream_t st) {
     static const int fu_env = []() { const char* e = getenv("CP360_E2C_FU"); return e ? atoi(e) : 0; }();
-    static const int cap_env = []() { const char* e = getenv("CP360_E2C_CAP"); return e ? atoi(e) : 64; }();
-    const int fu = (fu_env == 8 || (fu_env == 0 && false)) ? 8 : (fu_env == 2 ? 2 : 4);
+    static const int cap_env = []() { const char* e = getenv("CP360_E2C_CAP"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v; }();
+    const int fu = fu_env == 8 ? 8 : (fu_env == 2 ? 2 : 4);
     const long long total = (long long)((F + fu - 1) / fu) * 6 * cd * cd;      // one thread per pixel and group of FU frames
     long long blocks = (total + 255) / 256;
     if (blocks > 256LL * cap_env) blocks = 256LL * cap_env;

@@ -237,7 +237,9 @@ extern "C" int cp360_resize_lanczos_u8(const void* in, void* out, void* tmp, int
     static const int slow = []() { const char* e = getenv("CP360_RESIZE_BYTEWISE"); return e ? atoi(e) : 0; }();   // A/B switch
     if (need_h) {       // [F, h_in, w_in] -> [F, h_in, w_out]
         uint8_t* dst = need_v ? (uint8_t*)tmp : (uint8_t*)out;
-        if (!slow && h_window_fits(w_in, w_out, hksize) && (long long)F * h_in < (1 << 24)) {
+        // (the window kernel loads aligned dwords relative to the input base: a base that is not 4-byte aligned - a slice
+        // of a batch of odd-sized images - takes the bytewise pass)
+        if (!slow && h_window_fits(w_in, w_out, hksize) && (long long)F * h_in < (1 << 24) && (reinterpret_cast<size_t>(cur) & 3) == 0) {
             const int xblocks = (w_out + 255) / 256;
             long long items = (long long)F * h_in * xblocks;
             unsigned blocks = (unsigned)(items > 256 * 16 ? 256 * 16 : (items + 7) / 8 * 8);

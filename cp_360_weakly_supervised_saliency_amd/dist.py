@@ -47,16 +47,17 @@ def shard_clips(n_clips, rank, world):
 
 
 def gather_maps(local_maps, n_clips, rank, world):
-    """local_maps: [len(shard_clips(...)), h, w] f32 on this rank's device.
-    Returns [n_clips, h, w] on every rank, ordered by clip id (one all_gather)."""
+    """local_maps: [len(shard_clips(...)), h, w] f32 on this rank's device - or [.., T, h, w] with the per-step
+    maps of ``return_all_steps`` (any trailing shape).  Returns [n_clips, ...] on every rank, ordered by clip id
+    (one all_gather: 6 KB per rank at BASELINE config C4, 100 KB with all 16 per-step maps)."""
     if world == 1 and not dist.is_initialized():
         return local_maps
     base, extra = divmod(n_clips, world)
     cap = base + (1 if extra else 0)
-    h, w = local_maps.shape[1:]
-    send = torch.zeros((cap, h, w), dtype=local_maps.dtype, device=local_maps.device)
+    tail = tuple(local_maps.shape[1:])
+    send = torch.zeros((cap,) + tail, dtype=local_maps.dtype, device=local_maps.device)
     send[: local_maps.shape[0]] = local_maps
-    recv = torch.empty((world, cap, h, w), dtype=local_maps.dtype, device=local_maps.device)
+    recv = torch.empty((world, cap) + tail, dtype=local_maps.dtype, device=local_maps.device)
     dist.all_gather_into_tensor(recv, send) if hasattr(dist, 'all_gather_into_tensor') and \
         dist.get_backend() != 'gloo' else dist.all_gather(list(recv.unbind(0)), send)
     parts = [recv[r, : base + (1 if r < extra else 0)] for r in range(world)]
@@ -70,6 +71,16 @@ def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_ranks(value, device):
+    """The scalar of every rank, as a list ordered by rank (diagnosis output of bench.py)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(v.item()) for v in out]
 
 
 def barrier():

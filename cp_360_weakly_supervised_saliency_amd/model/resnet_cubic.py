@@ -33,6 +33,7 @@ FUSE_LAYER3 = True
 FUSE_STEM_POOL = os.environ.get('CP360_FUSE_STEM_POOL', '1') != '0'    # A/B switch: 0 = stem kernel, then max-pool kernel
 LAUNCH_ORDER = int(os.environ.get('CP360_LAUNCH_ORDER', '2'))   # 0: every launch ascending (A/B switch)
 FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
+CHAIN_L1_L2 = True         # layer2.0's conv1 (256 -> 128) chained onto layer1's last tail kernel (csrc/l1block.hip, wide)
 
 
 
@@ -99,9 +100,10 @@ class Bottleneck(nn.Module):
             self._plan, self._plan_stamp = plan, stamp
         return self._plan
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, mid=None):
+        """``mid``: this block's conv1 + bn1 + relu output when the previous layer's tail kernel already computed it."""
         p = self._plans()
-        out = p['c1'](x)
+        out = p['c1'](x) if mid is None else mid
         out = p['c2'](out)
         if p['c3'].second is not None:
             return p['c3'](out, x2=x)              # conv3 + bn3 + downsample(x) + relu in one tile
@@ -207,22 +209,31 @@ class ResNet(nn.Module):
     def _layer1_fused(self):
         """ops.L1Block per Bottleneck of layer1 (K3d), rebuilt when a parameter changes."""
         dt = _DTYPES[self.precision]
-        stamp = _stamp(self.layer1, (self.precision,))
+        l2c = self.layer2[0]
+        chain2 = bool(CHAIN_L1_L2 and tuple(l2c.conv1.weight.shape[:2]) == (128, 256) and list(self.layer1)[-1].downsample is None)
+        stamp = _stamp(self.layer1, (self.precision, chain2)) + (_stamp(l2c.conv1) + _stamp(l2c.bn1) if chain2 else ())
         if getattr(self, '_l1', None) is None or stamp != self._l1_stamp:
             dev = self.conv1.weight.device
             blks = list(self.layer1)
             out = []
             for k, b in enumerate(blks):
                 c = lambda conv, bn: (conv.weight,) + _fold_bn(bn)
-                nxt = c(blks[k + 1].conv1, blks[k + 1].bn1) if k + 1 < len(blks) else None
+                nxt = c(blks[k + 1].conv1, blks[k + 1].bn1) if k + 1 < len(blks) else \
+                    (c(l2c.conv1, l2c.bn1) if chain2 else None)
                 ds = c(b.downsample[0], b.downsample[1]) if b.downsample is not None else None
                 out.append(ops.L1Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), ds, nxt, dt, dev))
             self._l1, self._l1_stamp = out, stamp
         return self._l1
 
-    def layer1_nhwc(self, x):
+    def layer1_nhwc(self, x, want_next=False):
         """layer1 on the fused path.  16-bit types at 56x56 faces: conv1 of the first block, then ONE launch per
-        Bottleneck (conv2 -> conv3 + residual / downsample -> the next block's conv1, csrc/l1block.hip)."""
+        Bottleneck (conv2 -> conv3 + residual / downsample -> the next block's conv1, csrc/l1block.hip).
+        want_next: return (out, mid2) with mid2 = layer2.0's conv1 + bn1 + relu output when the last tail kernel
+        computed it (else None)."""
+        out, mid2 = self._layer1(x)
+        return (out, mid2) if want_next else out
+
+    def _layer1(self, x):
         dt = _DTYPES[self.precision]
         blks = list(self.layer1)
         if not (FUSE_LAYER1 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] and x.shape[1] in (56, 128)
@@ -230,21 +241,21 @@ class ResNet(nn.Module):
                 and all(b.downsample is None for b in blks[1:])):
             for blk in blks:
                 x = blk.forward_nhwc(x)
-            return x
+            return x, None
         fused = self._layer1_fused()
         mid = blks[0]._plans()['c1'](x)
         out, mid = fused[0](mid, x_ds=x)
         for k in range(1, len(blks)):
             out, mid = fused[k](mid, residual=out)
-        return out
+        return out, mid                               # mid: layer2.0's conv1 output (CHAIN_L1_L2), else None
 
-    def layer2_nhwc(self, x):
+    def layer2_nhwc(self, x, mid0=None):
         """layer2 on the fused path.  16-bit types at 28x28 output faces: the identity blocks run conv1 as a
         convolution and conv2 -> conv3 + residual as ONE launch (csrc/l2block.hip); the first (stride-2,
         downsample) block stays on the per-convolution path."""
         dt = _DTYPES[self.precision]
         blks = list(self.layer2)
-        x = blks[0].forward_nhwc(x)
+        x = blks[0].forward_nhwc(x, mid=mid0)          # mid0: conv1 of the first block, from layer1's last tail kernel
         if not (FUSE_LAYER2 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] and x.shape[1] in (28, 64)
                 and all(b.downsample is None and b.stride == 1 for b in blks[1:])):
             for blk in blks[1:]:
@@ -296,8 +307,8 @@ class ResNet(nn.Module):
         # lines its producer wrote last, still in the 256 MB Infinity Cache (ops.launch_order, tools/mall_probe.hip)
         with ops.launch_order(LAUNCH_ORDER):
             x = self.stem_nhwc(x_nhwc4, padded)
-            x = self.layer1_nhwc(x)
-            x = self.layer2_nhwc(x)
+            x, mid2 = self.layer1_nhwc(x, want_next=True)
+            x = self.layer2_nhwc(x, mid2)
             x = self.layer3_nhwc(x)
             for blk in self.layer4:
                 x = blk.forward_nhwc(x)
@@ -340,11 +351,24 @@ class ResNet(nn.Module):
         self.load_state_dict(own)
 
 
+# torchvision's public checkpoint of the architecture whose key names this module keeps (resnet_cubic.py:18-24)
+model_urls = {'resnet50': 'https://download.pytorch.org/models/resnet50-19c8e357.pth'}
+
+
 def resnet50(pretrained=False, **kwargs):
-    """ResNet-50-cubic.  ``pretrained=True`` would download ImageNet weights in the
-    reference (resnet_cubic.py:228-237); there is no network here, so pass a state dict
-    to ``load_pretrained_model`` / ``load_state_dict`` instead."""
+    """ResNet-50-cubic.  ``pretrained=True`` loads the ImageNet weights exactly as the reference does
+    (resnet_cubic.py:228-237: ``model.load_pretrained_model(model_zoo.load_url(model_urls['resnet50']))`` - torch's
+    hub cache is consulted first, so a checkpoint placed in ``$TORCH_HOME/hub/checkpoints`` works offline).  Only
+    when neither the cache nor the network can provide the file does it raise, naming the alternative
+    (``load_pretrained_model`` / ``load_state_dict`` with a state dict)."""
     model = ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)
     if pretrained:
-        raise RuntimeError("pretrained=True needs a download; load a state_dict instead")
+        import torch.utils.model_zoo as model_zoo
+        try:
+            state = model_zoo.load_url(model_urls['resnet50'], map_location='cpu')
+        except Exception as e:                       # no network and nothing cached
+            raise RuntimeError("resnet50(pretrained=True): could not fetch %s (%s: %s); put the checkpoint into torch's "
+                               "hub cache or call load_pretrained_model(state_dict)"
+                               % (model_urls['resnet50'], type(e).__name__, e)) from e
+        model.load_pretrained_model(state)
     return model

@@ -480,12 +480,15 @@ class L1Block:
             self.wd = frag_pack_1x1(wd, sd, dtype, 0, self.device)
             self.b3 = (self.b3 + f32(bd)).contiguous()
         self.w1 = self.b1 = None
+        self.next_c = 0
         if next_conv1 is not None:
             w1, s1, b1 = next_conv1
-            if tuple(w1.shape[:2]) != (64, 256):
-                raise ValueError("the chained conv1 is 256->64")
+            # 256 -> 64: the next layer1 block's conv1; 256 -> 128: layer2.0's conv1 behind the LAST (identity) block
+            if tuple(w1.shape[:2]) not in ((64, 256), (128, 256)) or (w1.shape[0] == 128 and downsample is not None):
+                raise ValueError("the chained conv1 is 256->64, or 256->128 behind an identity block")
             self.w1 = frag_pack_1x1(w1, s1, dtype, 1, self.device)
             self.b1 = f32(b1)
+            self.next_c = int(w1.shape[0])
 
     def __call__(self, mid, residual=None, x_ds=None):
         """mid [n_img, n, n, 64] with n = 56 (cube 224) or 128 (cube 512); residual [n_img, n, n, 256] (identity blocks)
@@ -504,7 +507,12 @@ class L1Block:
             if t is not None and t.shape[3] not in (64, 256):
                 raise ValueError("dense NHWC tensors only")
         out = torch.empty((n_img, n, n, 256), dtype=self.dtype, device=mid.device)
-        nxt = None if self.w1 is None else torch.empty((n_img, n, n, 64), dtype=self.dtype, device=mid.device)
+        nxt = None if self.w1 is None else torch.empty((n_img, n, n, self.next_c), dtype=self.dtype, device=mid.device)
+        if self.next_c == 128:
+            check(lib().cp360_l1block_forward_wide(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
+                                                   ptr(self.b3), ptr(residual), ptr(out), ptr(self.w1), ptr(self.b1),
+                                                   ptr(nxt), n_img, n, stream()))
+            return out, nxt
         check(lib().cp360_l1block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
                                           ptr(self.b3), ptr(residual), ptr(x_ds), ptr(self.wd), ptr(out), ptr(self.w1),
                                           ptr(self.b1), ptr(nxt), n_img, n, stream()))

@@ -30,7 +30,8 @@ from .utils.resize import LanczosResize
 class SaliencyEngine:
     def __init__(self, resnet_state, clstm_state, equi_hw=(1024, 2048), cube_dim=224, clips=1, frames=16,
                  precision='fp32', device='cuda', align_corners=False, cv_fixed_point=True,
-                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None, static_precision=None):
+                 input_size=1000, hidden_size=1000, frame_chunk=None, source_hw=None, static_precision=None,
+                 return_all_steps=False):
         self.device = torch.device(device)
         # ``precision`` is the arithmetic type of the temporal stage (the ConvLSTM: 81 % of the flops);
         # ``static_precision`` that of the static stage (cube projection output, ResNet-50, CAM conv).  The
@@ -40,8 +41,17 @@ class SaliencyEngine:
         # runs in; fp16 ResNet + bf16 ConvLSTM -> 5.2e-4, dCC 2.2e-4.
         self.precision = precision
         self.static_precision = static_precision or ('fp16' if precision == 'bf16' else precision)
+        # fp16 has a 5-bit exponent (max 65504) where bf16 has f32's range.  When the fp16 static stage was chosen BY
+        # DEFAULT for a bf16 engine, the first batch is checked once: non-finite CAM scores (a checkpoint whose
+        # folded-BN scales / activations exceed fp16's range) switch the static stage to bf16 - never silently wrong:
+        # ``static_precision`` / ``fp16_fallback`` say what runs, and bench.py reports them.  An explicit
+        # static_precision='fp16' (or precision='fp16') is honoured as given; ``nonfinite()`` lets a caller check any batch.
+        self._guard_pending = static_precision is None and precision == 'bf16'
+        self.fp16_fallback = False
         self.dtype = _lib.precision_dtype(self.static_precision)
         self.B, self.T = int(clips), int(frames)
+        # True: one map per ConvLSTM step, [B, T, 2w, 4w]; False: the window's final map [B, 2w, 4w]
+        self.return_all_steps = bool(return_all_steps)
         self.H, self.W = equi_hw
         self.cube_dim = int(cube_dim)
         self.w = self.cube_dim // 32
@@ -84,7 +94,7 @@ class SaliencyEngine:
         return self.cam
 
     def temporal_stage(self, cam=None):
-        return self.runner.run(self.cam if cam is None else cam)
+        return self.runner.run(self.cam if cam is None else cam, return_all_steps=self.return_all_steps)
 
     # ---- hipGraph replay (launch-bound small configurations: one frame / one clip)
     def capture(self, frames):
@@ -105,15 +115,33 @@ class SaliencyEngine:
             self._graph = g
         return self
 
+    def nonfinite(self):
+        """True when the last batch's CAM scores hold an inf / NaN (one device reduction + a sync: a check to run on
+        demand, not inside the hot loop).  With an fp16 static stage this is how activations beyond 65504 show."""
+        return not bool(torch.isfinite(self.cam).all())
+
+    def _fallback_to_bf16(self):
+        self.resnet.set_precision('bf16')                  # plans are re-packed on the next call (the stamp changed)
+        self.static_precision = 'bf16'
+        self.dtype = _lib.precision_dtype('bf16')
+        self.fp16_fallback = True
+
     def _forward(self, frames):
         B, T = frames.shape[:2]
         if (B, T) != (self.B, self.T):
             raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
-        self.static_stage(frames.reshape((B * T,) + tuple(frames.shape[2:])))
+        flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
+        self.static_stage(flat)
+        if self._guard_pending:                            # first batch only (and never during graph capture)
+            self._guard_pending = False
+            if self.static_precision == 'fp16' and self.nonfinite():
+                self._fallback_to_bf16()
+                self.static_stage(flat)
         return self.temporal_stage()
 
     def __call__(self, frames):
-        """frames [B, T, H, W, 3] (u8 or f32, device) -> saliency f32 [B, 2w, 4w]."""
+        """frames [B, T, H, W, 3] (u8 or f32, device) -> saliency f32 [B, 2w, 4w] ([B, T, 2w, 4w] with
+        ``return_all_steps``)."""
         with torch.no_grad():
             if getattr(self, '_graph', None) is not None:
                 if frames.shape != self._graph_in.shape or frames.dtype != self._graph_in.dtype:

@@ -26,9 +26,13 @@ class ClipRunner:
         self.minmax = torch.empty((self.B, 2), dtype=torch.float32, device=dev)
         self.scratch = torch.empty((self.B * 256 * 2,), dtype=torch.float32, device=dev)
 
-    def run(self, cam, return_hidden=False, sliding=False):
+    def run(self, cam, return_hidden=False, sliding=False, return_all_steps=False):
         """cam: f32 [B, T, 6*w*w, C] (NHWC cube_feat of every frame of every window,
         frame-major) on the device.  Returns saliency f32 [B, 2w, 4w].
+
+        return_all_steps=True: the map of the hidden state after EVERY step of the window,
+        f32 [B, T, 2w, 4w] - ``[:, t]`` is test_temporal.py:82-85 applied to ``hidden`` after step t of the loop
+        :76-79 (the reference keeps only the last one; ``[:, T-1]`` is that map).
 
         sliding=True: ``cam`` is ONE feature sequence [B+T-1, 6*w*w, C] and window b covers
         frames b .. b+T-1 - the reference's stride-1 sliding window (test_temporal.py:57-65)
@@ -46,13 +50,16 @@ class ClipRunner:
         cur = 0
         per_clip = stride if sliding else T * P * cin
         ops.window_normalize(cam, self.minmax, self.xh, 0, None, B, T, 0, P, cin, stride)
+        steps = [] if return_all_steps else None
         for t in range(T):
             # frame t+1's normalisation rides on step t's gate kernel (its x half of xh is free by then)
             nxt = (cam, self.minmax, P, per_clip, t + 1) if t + 1 < T else None
             self.cell.step_nhwc(self.xh, self.c[cur], self.c[cur ^ 1],
-                                self.h_f32 if t == T - 1 else None, bufs=self.a, x_next=nxt)
+                                self.h_f32 if (t == T - 1 or return_all_steps) else None, bufs=self.a, x_next=nxt)
             cur ^= 1
-        sal = self.c2e.saliency(self.h_f32, layout='nhwc')
+            if return_all_steps:
+                steps.append(self.c2e.saliency(self.h_f32, layout='nhwc'))
+        sal = torch.stack(steps, dim=1) if return_all_steps else self.c2e.saliency(self.h_f32, layout='nhwc')
         return (sal, self.h_f32) if return_hidden else sal
 
 

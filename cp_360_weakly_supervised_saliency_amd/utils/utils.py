@@ -101,11 +101,36 @@ def overlay(img, heatmap, cmap='jet', alpha=0.5, square=False):
     return Image.fromarray(out.cpu().numpy())
 
 
+def im_norm(in_img, mean, std):
+    """utils/utils.py:28-33 - the host-side per-channel ``(x - mean) / std`` of the reference's static driver
+    (dataset_feat_extractor.py:148-151), IN PLACE on the [H, W, 3] array like the reference (it returns the
+    same object).  Host glue of the module boundary: the fused device path does this inside K1
+    (``Equi2Cube.to_cube_batch``); this function exists so the reference's driver loop runs unchanged."""
+    out_img = in_img
+    for c in range(3):
+        out_img[:, :, c] = (in_img[:, :, c] - mean[c]) / std[c]
+    return out_img
+
+
+def sigmoid(x):
+    """utils/utils.py:36-37."""
+    return 1 / (1 + np.exp(-x))
+
+
 def cam_visual(input_equi, cam):
-    """utils/utils.py:40-45: normalise the CAM to 0..255 uint8 and overlay it.  (The reference hands the 2-D
-    uint8 array to ``overlay``, whose colormap call then INDEXES the table with those integers.)"""
-    cam = np.asarray(cam, dtype=np.float64)
+    """utils/utils.py:40-45: ``cam - min``, ``/ max``, ``np.uint8(255 * cam)`` in the INPUT's floating type (a
+    float32 CAM is scaled and truncated in float32, as numpy does for the reference), then ``overlay``.  There the
+    reference re-normalises the uint8 array (``- min`` = 0, ``/ max`` -> float64 ``k / 255``) and takes the FLOAT
+    path of the colormap: entry ``int(k / 255 * 256)`` = ``k`` for k < 255 and the clipped 256 -> 255 for k = 255,
+    i.e. exactly the table entry k - so the lookup below is the same RGB image without the round trip (a map
+    whose uint8 maximum is below 255 is re-stretched by that second normalisation: handled the same way)."""
+    cam = np.asarray(cam)
+    if cam.dtype.kind != 'f':
+        cam = cam.astype(np.float64)                      # numpy's true division of integer arrays
     cam = cam - np.min(cam)
     cam = cam / np.max(cam)
     idx = np.uint8(255 * cam)
+    k = idx.astype(np.float64) / np.float64(idx.max()) if idx.max() != 255 else None
+    if k is not None:                                     # the second normalisation is not the identity
+        idx = np.minimum((k * 256).astype(np.int64), 255).astype(np.uint8)
     return overlay(input_equi, jet_lut()[idx])

@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 211
+#define CP360_VERSION 300
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -299,6 +299,15 @@ int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, con
                           const void* w3_frags, const float* bias3, const void* residual, const void* x_ds,
                           const void* wd_frags, void* out, const void* w1_frags, const float* bias1,
                           void* out_next, int n_img, int face, void* stream);
+
+/* The LAST Bottleneck of layer1 (identity residual) chained with layer2's first conv1 (1x1, 256 -> 128 + bn1 + relu,
+ * model/resnet_cubic.py:88-90 of layer2.0) - the launch that would otherwise re-read the 616 MB (64 frames) this kernel
+ * writes.  Arguments as cp360_l1block_forward with residual (no x_ds); w1_frags = cp360_frag_pack_1x1(w1 [128, 256],
+ * order 1), bias1 f32 [128] or NULL, out_next [n_img, face, face, 128].  56x56 and 128x128 faces, CP360_BF16 / CP360_F16. */
+int cp360_l1block_forward_wide(int dtype, const void* mid, const void* w2_packed, const float* bias2,
+                               const void* w3_frags, const float* bias3, const void* residual, void* out,
+                               const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
+                               void* stream);
 
 /* ------------------------------------------------------------------ K3e: fused Bottleneck tail (layer2)
  * conv2 (CubePad(1) + 3x3, 128 -> 128) + bn2 + relu -> conv3 (1x1, 128 -> 512) + bn3 + identity residual + relu

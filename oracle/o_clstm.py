@@ -32,23 +32,26 @@ def clstm_step(x, hidden, cell, sd):
     return hidden, cell
 
 
-def window_hidden(frames, sd):
+def window_hidden(frames, sd, all_steps=False):
     """test_temporal.py:63-80 for ONE window.
 
     frames: ndarray [T, 6, C, w, w] float32 (the T cube_feat arrays of the window).
     mn/mx over the whole window (:66-67); hidden = cell = normalised frame 0
     (:70-73); all T frames (frame 0 again first) are fed in order (:76-79);
-    returns the final hidden [6, C, w, w] float32.
+    returns the final hidden [6, C, w, w] float32 (all_steps: the hidden after every step, [T, 6, C, w, w]).
     """
     frames = np.asarray(frames, dtype=np.float32)
     mx, mn = np.max(frames), np.min(frames)
     init = (frames[0] - mn) / (mx - mn)
     hidden = torch.from_numpy(init.astype(np.float32))
     cell = torch.from_numpy(init.astype(np.float32))
+    trace = []
     for t in range(frames.shape[0]):
         f = torch.from_numpy(((frames[t] - mn) / (mx - mn)).astype(np.float32))
         hidden, cell = clstm_step(f, hidden, cell, sd)
-    return hidden.numpy()
+        if all_steps:
+            trace.append(hidden.numpy().copy())
+    return np.stack(trace) if all_steps else hidden.numpy()
 
 
 def window_saliency(frames, sd, face_map=None, out_coord=None, align_corners=False):

@@ -28,14 +28,21 @@ def _fake_saliency(clip_id):
     return r.rand(14, 28).astype(np.float32)
 
 
-def _worker(rank, world, port, n_clips, q):
+def _fake_steps(clip_id, T=3):
+    """Stand-in for a clip's per-step maps [T, 14, 28] (``return_all_steps``)."""
+    return np.stack([_fake_saliency(1000 * (t + 1) + clip_id) for t in range(T)])
+
+
+def _worker(rank, world, port, n_clips, q, all_steps=False):
     sys.path.insert(0, REPO)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     from cp_360_weakly_supervised_saliency_amd import dist as d
     r, w, _ = d.init_from_env(backend='gloo')
     mine = d.shard_clips(n_clips, r, w)
-    local = torch.from_numpy(np.stack([_fake_saliency(c) for c in mine])) if mine else torch.zeros((0, 14, 28))
+    fake = _fake_steps if all_steps else _fake_saliency
+    empty = (0, 3, 14, 28) if all_steps else (0, 14, 28)
+    local = torch.from_numpy(np.stack([fake(c) for c in mine])) if mine else torch.zeros(empty)
     d.barrier()
     allmaps = d.gather_maps(local, n_clips, r, w)
     t = d.max_over_ranks(1.0 + r, 'cpu')
@@ -62,6 +69,24 @@ def test_two_rank_gather_equals_single_process(n_clips):
         assert t == 2.0
         owned += mine
     assert sorted(owned) == list(range(n_clips))
+
+
+@pytest.mark.parametrize('n_clips', [4, 3])
+def test_two_rank_gather_of_per_step_maps(n_clips):
+    """``return_all_steps``: [clips_per_rank, T, 2w, 4w] goes through the same single all-gather (ragged too)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_clips, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([_fake_steps(c) for c in range(n_clips)])
+    for rank, mine, allmaps, t in res:
+        assert allmaps.shape == want.shape == (n_clips, 3, 14, 28) and np.array_equal(allmaps, want)
 
 
 def test_shard_is_balanced_partition():

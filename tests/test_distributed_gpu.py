@@ -13,12 +13,21 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_rccl_single_rank_through_torchrun():
     env = dict(os.environ, CP360_DIST_FORCE_PG='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
-           '--master-addr', '127.0.0.1', '--master-port', '29541',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(REPO, 'tests', '_torchrun_worker.py'), '5']
     r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

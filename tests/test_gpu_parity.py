@@ -305,6 +305,15 @@ def test_layer1_fused_block_kernel_cube512_faces(prec):
         rc.FUSE_LAYER1 = True
     assert got.shape == (6, 128, 128, 256)
     assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    # torch-CPU layer1 (resnet_cubic.py:85-106 on cube-padded input) in f32 from the same 16-bit input
+    from oracle import o_resnet
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xc = x.float().cpu().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for b in range(3):
+            xc = o_resnet._bottleneck(xc, sdt, 'layer1.%d' % b, 1, b == 0)
+        want = xc.permute(0, 2, 3, 1).numpy()
+    assert rel_err(got, want) <= 4 * _TOL[prec], rel_err(got, want)
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
@@ -337,6 +346,37 @@ def test_layer1_fused_block_kernel(prec, n_img):
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('face', [56, 128])
+def test_layer1_last_tail_chains_layer2_conv1(prec, face):
+    """csrc/l1block.hip, l1block_wide_kernel: layer1's last Bottleneck tail also computes layer2.0's conv1 + bn1 + relu
+    (256 -> 128, resnet_cubic.py:88-90) from its output pieces.  out == the unchained tail bit for bit; mid2 vs the
+    per-convolution conv1 on the SAME rounded out (same operands, f32 accumulate) and vs torch-CPU; and layer2 fed
+    with mid2 == layer2 computing its own conv1."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4550 + face, (6, face, face, 64), 0.0, 1.0))).to(DEV).to(dt)
+    out, mid2 = m.layer1_nhwc(x, want_next=True)
+    assert mid2 is not None and tuple(mid2.shape) == (6, face, face, 128)
+    rc.CHAIN_L1_L2 = False
+    try:
+        out_u, none = m.layer1_nhwc(x, want_next=True)
+    finally:
+        rc.CHAIN_L1_L2 = True
+    assert none is None and torch.equal(out, out_u)
+    c1 = m.layer2[0]._plans()['c1'](out)
+    assert rel_err(mid2.float().cpu().numpy(), c1.float().cpu().numpy()) <= _TOL[prec]
+    s1 = sd['layer2.0.bn1.weight'] / np.sqrt(sd['layer2.0.bn1.running_var'] + 1e-5)
+    b1 = sd['layer2.0.bn1.bias'] - sd['layer2.0.bn1.running_mean'] * s1
+    want = torch.relu(Fn.conv2d(out.float().cpu().permute(0, 3, 1, 2), torch.from_numpy(sd['layer2.0.conv1.weight']))
+                      * torch.from_numpy(s1)[None, :, None, None] + torch.from_numpy(b1)[None, :, None, None])
+    assert rel_err(mid2.float().cpu().numpy(), want.permute(0, 2, 3, 1).numpy()) <= _TOL[prec]
+    y_chain = m.layer2_nhwc(out, mid2).float().cpu().numpy()
+    y_own = m.layer2_nhwc(out).float().cpu().numpy()
+    assert rel_err(y_chain, y_own) <= _TOL[prec]
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 def test_layer2_fused_tail_kernel_cube512_faces(prec):
     """K3e at 64x64 faces (cube 512, BASELINE config C5): bands of two output rows (128 pixels = 8 pixel blocks)."""
     from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
@@ -351,6 +391,15 @@ def test_layer2_fused_tail_kernel_cube512_faces(prec):
         rc.FUSE_LAYER2 = True
     assert got.shape == (6, 64, 64, 512)
     assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    # torch-CPU layer2 (resnet_cubic.py:85-106) in f32 from the same 16-bit input
+    from oracle import o_resnet
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xc = x.float().cpu().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for b in range(4):
+            xc = o_resnet._bottleneck(xc, sdt, 'layer2.%d' % b, 2 if b == 0 else 1, b == 0)
+        want = xc.permute(0, 2, 3, 1).numpy()
+    assert rel_err(got, want) <= 4 * _TOL[prec], rel_err(got, want)
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
@@ -873,9 +922,9 @@ def test_sliding_window_mode_equals_per_window(full_cell_state):
 
 def test_pipeline_c5_shape_fp32_and_fp16():
     """BASELINE config C5 geometry: 2048x4096 equirectangular, 6x512^2 cube faces, layer4 / ConvLSTM
-    at 16x16, saliency 32x64 - two frames against the oracle: fp32 within the 1e-3 north-star bound,
-    fp16 (C5's MFMA precision) by the AUC-Judd / CC gate of SURVEY 8(d)."""
-    H, W, cd, T = 2048, 4096, 512, 2
+    at 16x16, saliency 32x64 - one full 16-frame clip (the length bench.py's C5 line runs) against the oracle:
+    fp32 within the 1e-3 north-star bound, fp16 (C5's MFMA precision) by the AUC-Judd / CC gate of SURVEY 8(d)."""
+    H, W, cd, T = 2048, 4096, 512, 16
     rs = synth.resnet50_state(seed=1)
     cs = synth.clstm_state(seed=2)
     clip = synth.clip_u8(50, T, H, W)

@@ -63,6 +63,8 @@ for v in variants:
     if v == 'clip_nobar2':     # clip kernel: drop the second barrier of a sub-step (racy: timing only)
         sub("            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n            __builtin_amdgcn_s_barrier();                                                                  \\\n",
             "            if (!LAG) CP360_CLIP_HEAD(REFILL) else CP360_CLIP_TAIL()                                       \\\n            __builtin_amdgcn_sched_barrier(0);                                                             \\\n")
+    if v == 'clip_center':     # clip kernel: every tap reads the centre tap's rows (consecutive rows: no bank conflicts) - the upper bound of what a conflict-free layout of the resident tile can gain (timing only)
+        sub('src = cubepad_src(f, y + t / 3, x + t % 3, geom);          // pixel index inside the clip', 'src = cubepad_src(f, y + 1, x + 1, geom);')
     if v == 'clip_notab':      # clip kernel: no per-tap table loads (entries of tap 0 throughout)
         sub('            load_ent(tap);                                                                                 \\\n        }', '        }')
     if v == 'clip_decode_head':   # clip kernel: decode the B addresses at the START of a HEAD (the round-1 placement) instead of in the TAIL

@@ -7,8 +7,9 @@ their rate is a cache rate, which is also how they run inside the pipeline (prod
 
     python tools/hbm_kernels.py [--md profiles/r02_hbm_kernels.md] [--json profiles/r02_hbm_kernels.json]
 
-The same script under rocprofv3 (--pmc FETCH_SIZE / WRITE_SIZE, separate passes: tools/pmc_hbm_kernels.sh) gives the
-counter-side bytes per kernel.
+The same script under rocprofv3 (`rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/hbm_kernels.py`, then the
+same with WRITE_SIZE: separate passes, as tools/collect_profile.sh does for bench.py) gives the counter-side bytes per
+kernel.
 """
 import argparse
 import json
