@@ -102,14 +102,24 @@ def roofline_pass(eng, frames, precision, steps=2):
     """Dominant kernel = the K = 36000 ConvLSTM convolutions (Conv2 / Gates have the same shape):
     algorithmic flops of one launch / its mean duration over `steps` extra steps, every launch
     bracketed by HIP events on the launch stream."""
+    # the timed region runs each stage through ONE C call (cp360_resnet_forward / cp360_clstm_step); to bracket single
+    # launches with events this pass plans the SAME launch sequence from Python (CP360_CTX=0 path: same kernels, same
+    # descriptors, bit-identical results - tests/test_ctx.py)
+    from cp_360_weakly_supervised_saliency_amd import stage_ctx
     timer = LaunchTimer()
     ops.LAUNCH_TIMER = timer
-    timer.active = True
-    for _ in range(steps):
-        eng(frames)
-    torch.cuda.synchronize()
-    timer.active = False
-    ops.LAUNCH_TIMER = None
+    old_ctx, stage_ctx.USE_CTX = stage_ctx.USE_CTX, False
+    try:
+        eng(frames)                                    # packs the Python-side plan (untimed)
+        torch.cuda.synchronize()
+        timer.active = True
+        for _ in range(steps):
+            eng(frames)
+        torch.cuda.synchronize()
+    finally:
+        timer.active = False
+        ops.LAUNCH_TIMER = None
+        stage_ctx.USE_CTX = old_ctx
     n, ms, flops = timer.summary()
     if not n:
         return None

@@ -44,6 +44,8 @@ SYMBOLS = [
     'cp360_resize_linear_f32', 'cp360_metric_work_bytes', 'cp360_metric_auc_prepare', 'cp360_metric_auc_judd',
     'cp360_metric_auc_borji', 'cp360_metric_cc_sim',
     'cp360_resize_ksize2', 'cp360_resize_coeffs_host2', 'cp360_overlay_colorize', 'cp360_overlay_blend_u8',
+    'cp360_fold_bn', 'cp360_create', 'cp360_destroy', 'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward',
+    'cp360_clstm_load', 'cp360_clstm_workspace_bytes', 'cp360_clstm_step',
 ]
 
 
@@ -54,6 +56,11 @@ class ConvDesc(C.Structure):
         'h_out', 'w_out', 'c_out', 'pad_mode', 'pad', 'ld_out', 'out_coff', 'ld_res',
         'relu', 'splits', 'tile_px', 'clip_resident', 'slab_rows',
         'c_in2', 'pix_stride2', 'h_in2', 'w_in2', 'sy2', 'sx2')]
+
+
+class ConvBn(C.Structure):
+    """Mirror of ``cp360_conv_bn`` (include/cp360.h): device f32 pointers of one convolution + its BatchNorm."""
+    _fields_ = [(n, C.c_void_p) for n in ('weight', 'bn_weight', 'bn_bias', 'bn_mean', 'bn_var')]
 
 
 class Cp360Error(RuntimeError):
@@ -143,6 +150,18 @@ def lib():
     L.cp360_metric_auc_judd.argtypes = [i, vp, vp, vp]
     L.cp360_metric_auc_borji.argtypes = [i, i, vp, C.c_double, vp, vp, vp]
     L.cp360_metric_cc_sim.argtypes = [vp, vp, i, vp, vp]
+    L.cp360_fold_bn.argtypes = [vp, vp, vp, vp, f, vp, vp, i, vp]
+    L.cp360_create.argtypes = [i, C.POINTER(vp)]
+    L.cp360_destroy.argtypes = [vp]
+    L.cp360_destroy.restype = None
+    L.cp360_resnet_load.argtypes = [vp, i, C.POINTER(ConvBn), i, vp, i, f, f, vp]
+    L.cp360_resnet_workspace_bytes.restype = sz
+    L.cp360_resnet_workspace_bytes.argtypes = [vp, i, i]
+    L.cp360_resnet_forward.argtypes = [vp, vp, i, i, vp, vp, vp, sz, vp]
+    L.cp360_clstm_load.argtypes = [vp, i, vp, vp, vp, vp, vp, vp, i, i, i, vp]
+    L.cp360_clstm_workspace_bytes.restype = sz
+    L.cp360_clstm_workspace_bytes.argtypes = [vp, i, i]
+    L.cp360_clstm_step.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, sz, vp, sz, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):

@@ -10,7 +10,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, stage_ctx
 from .._lib import PRECISIONS as _DTYPES
 from .cube_pad import CubePad
 
@@ -82,6 +82,13 @@ class ConvLSTMCell(nn.Module):
         c_prev / c_next [6B, w, w, Ch] f32; h_f32 optional f32 copy of the new hidden.
         x_next (ClipRunner): the next frame's window normalisation rides on the gate kernel (needs Cin == Ch).
         """
+        if stage_ctx.USE_CTX:
+            # ONE C call per cell update (cp360_clstm_step, csrc/ctx.hip); CP360_CTX=0 plans the same launches here
+            stage = self.__dict__.get('_stage')
+            if stage is None:
+                stage = self.__dict__['_stage'] = stage_ctx.ClstmStage(self)
+            stage.step(xh, c_prev, c_next, h_f32, x_next)
+            return
         p = self.plans()
         n6, w, _, _ = xh.shape
         a1 = p['c1'](xh, out=None if bufs is None else bufs[0])

@@ -38,12 +38,17 @@ CHAIN_L1_L2 = True         # layer2.0's conv1 (256 -> 128) chained onto layer1's
 
 
 def _fold_bn(bn):
-    """Eval-mode BatchNorm2d as y = x * scale + bias.  One-time parameter preparation
-    on the host in f32; the multiply into the weights happens in the pack kernel."""
-    g, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
-    mu, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
-    scale = g / torch.sqrt(var + bn.eps)
-    return scale, b - mu * scale
+    """Eval-mode BatchNorm2d as y = x * scale + bias (scale = g / sqrt(var + eps), bias = b - mean * scale; f32, one
+    rounding per operation): one-time parameter preparation by ``cp360_fold_bn`` on the device - the same folding
+    ``cp360_resnet_load`` applies; the multiply into the weights happens in the pack kernel."""
+    from .._lib import check, lib, ptr, require_gpu, stream
+    ts = [t.detach().float().contiguous() for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+    require_gpu(*ts)
+    n = ts[0].numel()
+    scale = torch.empty(n, dtype=torch.float32, device=ts[0].device)
+    bias = torch.empty_like(scale)
+    check(lib().cp360_fold_bn(ptr(ts[0]), ptr(ts[1]), ptr(ts[2]), ptr(ts[3]), float(bn.eps), ptr(scale), ptr(bias), n, stream()))
+    return scale, bias
 
 
 def _stamp(module, extra=()):

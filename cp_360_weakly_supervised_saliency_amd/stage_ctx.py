@@ -1,0 +1,172 @@
+"""``cp360_ctx`` (include/cp360.h, csrc/ctx.hip) from Python: one C call per network stage.
+
+The context owns the packed / BatchNorm-folded weights and ALL launch planning of a stage (which fused kernel runs
+where, tiles, split-K); the shims hand it the module's parameters once (``*_load``, repeated when a parameter
+changes) and then call ``cp360_resnet_forward`` / ``cp360_clstm_step`` with caller-owned activations and a torch-
+allocated workspace.  ``CP360_CTX=0`` keeps the launch planning in Python (ops.Conv / model/*: the per-kernel entry
+points) - both paths issue the same launches and give the same bits (tests/test_ctx.py).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from ._lib import ConvBn, check, dtype_code, lib, precision_dtype, ptr, require_gpu, stream
+
+USE_CTX = os.environ.get('CP360_CTX', '1') != '0'
+
+
+def _stamp(module, extra=()):
+    ts = list(module.parameters()) + list(module.buffers())
+    return tuple((t.data_ptr(), t._version) for t in ts) + tuple(extra)
+
+
+class StageCtx:
+    """A ``cp360_ctx`` handle bound to one device (destroyed with the object)."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError("cp360 contexts live on a GPU (HIP); there is no CPU fallback")
+        self.device = device
+        h = C.c_void_p()
+        check(lib().cp360_create(device.index if device.index is not None else torch.cuda.current_device(), C.byref(h)))
+        self.h = h
+        self._ws = {}
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            try:
+                lib().cp360_destroy(h)
+            except Exception:
+                pass
+
+    def workspace(self, key, nbytes):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = t
+        return t
+
+
+def _f32(t):
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+class ResnetStage:
+    """ResNet-50-cubic + CAM of ``model`` (model/resnet_cubic.py: ResNet) behind cp360_resnet_forward."""
+
+    def __init__(self, model):
+        self.model = model
+        self.ctx = None
+        self.stamp = None
+
+    def _load(self):
+        m = self.model
+        dev = m.conv1.weight.device
+        require_gpu(m.conv1.weight)
+        stamp = _stamp(m, (m.precision, str(dev)))
+        if self.ctx is not None and stamp == self.stamp:
+            return
+        if self.ctx is None or self.ctx.device != dev:
+            self.ctx = StageCtx(dev)
+        keep = []                                          # f32 device tensors alive until the packing kernels are queued
+
+        def cb(conv, bn):
+            ts = [_f32(conv.weight), _f32(bn.weight), _f32(bn.bias), _f32(bn.running_mean), _f32(bn.running_var)]
+            keep.extend(ts)
+            return ConvBn(*[t.data_ptr() for t in ts])
+        pairs = [cb(m.conv1, m.bn1)]
+        eps = m.bn1.eps
+        for layer in (m.layer1, m.layer2, m.layer3, m.layer4):
+            for blk in layer:
+                pairs += [cb(blk.conv1, blk.bn1), cb(blk.conv2, blk.bn2), cb(blk.conv3, blk.bn3)]
+                if blk.downsample is not None:
+                    pairs.append(cb(blk.downsample[0], blk.downsample[1]))
+        arr = (ConvBn * len(pairs))(*pairs)
+        fc = _f32(m.fc.weight)
+        mn = float(fc.min())                               # class_activation_model.py:51-52 (one host sync per load)
+        check(lib().cp360_resnet_load(self.ctx.h, dtype_code(precision_dtype(m.precision)), arr, len(pairs), ptr(fc),
+                                      int(fc.shape[0]), mn if mn < 0 else 0.0, float(eps), stream()))
+        torch.cuda.current_stream().synchronize()          # the f32 sources (possibly temporaries) may go now
+        self.stamp = stamp
+
+    def forward(self, faces_p3, cam_out=None, want_feat=True):
+        """faces_p3 [6N, cd+6, cd+6, 4] (model dtype) -> (cam f32 [6N, h, w, classes], layer4 [6N, h, w, 2048] or None)."""
+        self._load()
+        m = self.model
+        dt = precision_dtype(m.precision)
+        require_gpu(faces_p3, cam_out)
+        if faces_p3.dtype != dt or not faces_p3.is_contiguous() or faces_p3.dim() != 4 or faces_p3.shape[3] != 4 \
+                or faces_p3.shape[1] != faces_p3.shape[2]:
+            raise ValueError("faces_p3 must be a contiguous %s [6N, cd+6, cd+6, 4] tensor" % dt)
+        n_img, cd = faces_p3.shape[0], faces_p3.shape[1] - 6
+        hw, nc = cd // 32, int(m.fc.weight.shape[0])
+        need = n_img * hw * hw * nc
+        if cam_out is None:
+            cam_out = torch.empty((n_img, hw, hw, nc), dtype=torch.float32, device=faces_p3.device)
+        elif cam_out.dtype != torch.float32 or not cam_out.is_contiguous() or cam_out.numel() < need:
+            raise ValueError("cam_out must be a contiguous f32 tensor of at least %d elements" % need)
+        feat = torch.empty((n_img, hw, hw, 2048), dtype=dt, device=faces_p3.device) if want_feat else None
+        nbytes = lib().cp360_resnet_workspace_bytes(self.ctx.h, n_img, cd)
+        if nbytes == 0:
+            raise ValueError("unsupported static-stage geometry: %d faces of %d^2" % (n_img, cd))
+        ws = self.ctx.workspace(('resnet', n_img, cd), nbytes)
+        check(lib().cp360_resnet_forward(self.ctx.h, ptr(faces_p3), n_img, cd, ptr(cam_out), ptr(feat), ptr(ws), ws.numel(),
+                                         stream()))
+        return cam_out.view(-1)[:need].view(n_img, hw, hw, nc), feat
+
+
+class ClstmStage:
+    """``ConvLSTMCell`` (model/clstm.py) behind cp360_clstm_step, for one face size."""
+
+    def __init__(self, cell):
+        self.cell = cell
+        self.ctx = None
+        self.stamp = None
+
+    def _load(self, face):
+        c = self.cell
+        dev = c.Conv1.weight.device
+        require_gpu(c.Conv1.weight)
+        stamp = _stamp(c, (c.precision, str(dev), int(face)))
+        if self.ctx is not None and stamp == self.stamp:
+            return
+        if self.ctx is None or self.ctx.device != dev:
+            self.ctx = StageCtx(dev)
+        ts = [_f32(t) for t in (c.Conv1.weight, c.Conv1.bias, c.Conv2.weight, c.Conv2.bias, c.Gates.weight, c.Gates.bias)]
+        check(lib().cp360_clstm_load(self.ctx.h, dtype_code(precision_dtype(c.precision)), *[ptr(t) for t in ts],
+                                     int(c.input_size), int(c.hidden_size), int(face), stream()))
+        torch.cuda.current_stream().synchronize()
+        self.stamp = stamp
+
+    def step(self, xh, c_prev, c_next, h_f32=None, x_next=None):
+        """One cell update on the fused layout (see ConvLSTMCell.step_nhwc); x_next = (cam, minmax, P, clip_stride, t_next)."""
+        n6, w = xh.shape[0], xh.shape[1]
+        self._load(w)
+        c = self.cell
+        dt = precision_dtype(c.precision)
+        require_gpu(xh, c_prev, c_next, h_f32)
+        if xh.dtype != dt or not xh.is_contiguous() or n6 % 6 or xh.shape[3] != c.input_size + c.hidden_size:
+            raise ValueError("xh must be a contiguous %s [6B, w, w, Cin + H] tensor" % dt)
+        for name, t in (('c_prev', c_prev), ('c_next', c_next), ('h_f32', h_f32)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < n6 * w * w * c.hidden_size):
+                raise ValueError("%s must be a contiguous f32 [6B, w, w, H] tensor" % name)
+        B = n6 // 6
+        nbytes = lib().cp360_clstm_workspace_bytes(self.ctx.h, B, w)
+        ws = self.ctx.workspace(('clstm', B, w), nbytes)
+        xp, mm, stride = None, None, 0
+        if x_next is not None:
+            cam, minmax, P, clip_stride, t_next = x_next
+            require_gpu(cam, minmax)
+            if cam.dtype != torch.float32 or minmax.dtype != torch.float32 or P != 6 * w * w \
+                    or cam.numel() < (B - 1) * clip_stride + (t_next + 1) * P * c.hidden_size or minmax.numel() < 2 * B:
+                raise ValueError("x_next: cam f32 with frame t_next of every clip, minmax f32 [B, 2]")
+            xp = C.c_void_p(cam.data_ptr() + 4 * t_next * P * c.hidden_size)
+            mm, stride = ptr(minmax), int(clip_stride)
+        check(lib().cp360_clstm_step(self.ctx.h, ptr(xh), ptr(c_prev), ptr(c_next), ptr(h_f32), B, w, xp, mm, stride, ptr(ws),
+                                     ws.numel(), stream()))

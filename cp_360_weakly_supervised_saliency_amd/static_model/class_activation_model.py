@@ -9,13 +9,21 @@ results the caller asked for cross PCIe.
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import _lib, ops, stage_ctx
 
 
 def cam_device(input_cubemap_nhwc4, model, out=None, padded=False):
     """Fused device path: normalised cube faces [6N, H, W, 4] (NHWC4, the output of
     ``Equi2Cube.to_cube_batch``) -> (cube_score f32 [6N, h, w, 1000] NHWC,
     layer4 features [6N, h, w, 2048] NHWC in the model's compute dtype)."""
+    if stage_ctx.USE_CTX:
+        # ONE C call for the whole static stage (cp360_resnet_forward, csrc/ctx.hip): the library owns the packed weights
+        # and the launch planning; CP360_CTX=0 plans the same launches from Python (below)
+        stage = model.__dict__.get('_stage')
+        if stage is None:
+            stage = model.__dict__['_stage'] = stage_ctx.ResnetStage(model)
+        xp = input_cubemap_nhwc4 if padded else ops.cubepad_nhwc(input_cubemap_nhwc4, 3)
+        return stage.forward(xp, cam_out=None if out is None else out.view(-1))
     feat = model.features_nhwc(input_cubemap_nhwc4, padded)      # padded: the faces already carry their CubePad(3) ring
     cam = model.cam_conv()
     n6, h, w, _ = feat.shape

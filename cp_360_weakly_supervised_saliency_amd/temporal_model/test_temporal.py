@@ -22,7 +22,9 @@ class ClipRunner:
         self.xh = torch.empty((n6, w, w, cin + ch), dtype=dt, device=dev)
         self.c = [torch.empty((n6, w, w, ch), dtype=torch.float32, device=dev) for _ in range(2)]
         self.h_f32 = torch.empty((n6, w, w, ch), dtype=torch.float32, device=dev)
-        self.a = [torch.empty((n6, w, w, 4 * ch), dtype=dt, device=dev) for _ in range(2)]
+        # (with the stage context the two intermediate activations live in its workspace)
+        from .. import stage_ctx
+        self.a = None if stage_ctx.USE_CTX else [torch.empty((n6, w, w, 4 * ch), dtype=dt, device=dev) for _ in range(2)]
         self.minmax = torch.empty((self.B, 2), dtype=torch.float32, device=dev)
         self.scratch = torch.empty((self.B * 256 * 2,), dtype=torch.float32, device=dev)
 

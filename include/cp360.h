@@ -425,6 +425,67 @@ int cp360_metric_auc_borji(int n, int n_splits, const int* rr, double step, void
 /* out2[0] = CorrCoeff(a, b), out2[1] = similarity(a, b) of two resized maps (doubles). */
 int cp360_metric_cc_sim(const float* a, const float* b, int n, double* out2, void* stream);
 
+/* ------------------------------------------------------------------ stage contexts: ONE entry point per network stage
+ * (csrc/ctx.hip).  A cp360_ctx owns the packed / BatchNorm-folded weights of the two networks and the kernel choice for
+ * every layer (fused tail kernels, tile shapes, split-K: everything the per-kernel entry points above leave to the
+ * caller), so a binder needs three calls per stage - load, workspace_bytes, forward - instead of re-implementing the
+ * launch planning.  The Python shims of this package call these (pipeline.py, static_model/class_activation_model.py:
+ * cam_device, temporal_model/test_temporal.py: ClipRunner); the per-kernel entry points stay for tests and tuning.
+ *  - a context is bound to one device; one context per GPU; not thread-safe within a context;
+ *  - weights are DEVICE f32 tensors in the reference's state-dict layout, read during *_load only (packed copies are
+ *    owned by the context, hipMalloc / hipFree inside load / destroy - the only allocations this library makes);
+ *  - activations, workspace and outputs are caller-allocated; `workspace` must be 256-byte aligned and at least
+ *    *_workspace_bytes(...) for the same shape; forward calls are asynchronous on `stream` and never allocate.
+ */
+/* Eval-mode BatchNorm2d as y = x * scale + bias (model/resnet_cubic.py:66-70 with eps 1e-5): scale = g / sqrt(var + eps),
+ * bias = b - mean * scale, each operation rounded once in f32 (IEEE divide / sqrt, no FMA contraction), all pointers
+ * device f32 [n].  The folding cp360_resnet_load applies; public so that a caller planning its own launches folds
+ * identically. */
+int cp360_fold_bn(const float* bn_weight, const float* bn_bias, const float* bn_mean, const float* bn_var, float eps,
+                  float* scale, float* bias, int n, void* stream);
+
+typedef struct cp360_ctx cp360_ctx;
+int cp360_create(int device, cp360_ctx** out);
+void cp360_destroy(cp360_ctx* ctx);
+
+/* One convolution + its BatchNorm (model/resnet_cubic.py:65-83,115-128): OIHW weight and the four BatchNorm vectors. */
+typedef struct {
+    const float* weight;
+    const float* bn_weight;
+    const float* bn_bias;
+    const float* bn_mean;
+    const float* bn_var;
+} cp360_conv_bn;
+
+/* ResNet-50-cubic + CAM.  convs[53] in torchvision's key order: conv1/bn1, then for layerL.B: conv1/bn1, conv2/bn2,
+ * conv3/bn3 and, for block 0 of a layer, downsample.0/downsample.1.  fc_weight [num_classes, 2048]; fc_shift = min(fc_weight)
+ * when that is negative, else 0 (class_activation_model.py:51-52: the global scalar shift, computed by the caller).
+ * dtype: CP360_F32 (exact-f32 MFMA path), CP360_BF16 or CP360_F16. */
+int cp360_resnet_load(cp360_ctx* ctx, int dtype, const cp360_conv_bn* convs, int n_convs, const float* fc_weight,
+                      int num_classes, float fc_shift, float bn_eps, void* stream);
+size_t cp360_resnet_workspace_bytes(cp360_ctx* ctx, int n_img, int cube_dim);
+/* faces_p3 [n_img, cube_dim+6, cube_dim+6, 4]: normalised cube faces WITH their CubePad(3) ring, NHWC4, in the loaded
+ * dtype (what cp360_equi2cube writes with the CubePad(3)-gathered grid) -> cam_out f32 [n_img, cd/32, cd/32, num_classes]
+ * (the per-face CAM scores of class_activation_model.py:70-83, NHWC) and, if feat_out != NULL, the layer4 features
+ * [n_img, cd/32, cd/32, 2048] in the loaded dtype.  resnet_cubic.py:163-175 + class_activation_model.py:46-83. */
+int cp360_resnet_forward(cp360_ctx* ctx, const void* faces_p3, int n_img, int cube_dim, float* cam_out, void* feat_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ConvLSTM cell (model/clstm.py:19-82).  w1 [4H, Cin+H, 3, 3], w2 / wg [4H, 4H, 3, 3], biases [4H]; `face` = the cube
+ * face size the cell will run at (7 at cube 224, 16 at cube 512): it selects the weight layout of the kernel for that size. */
+int cp360_clstm_load(cp360_ctx* ctx, int dtype, const float* w1, const float* b1, const float* w2, const float* b2,
+                     const float* wg, const float* bg, int input_size, int hidden_size, int face, void* stream);
+size_t cp360_clstm_workspace_bytes(cp360_ctx* ctx, int n_clips, int face);
+/* One cell update for n_clips cubes in lock step on the fused layout: xh [6 n_clips, face, face, Cin + H] (loaded dtype):
+ * channels [0, Cin) = the input frame, [Cin, Cin + H) = the previous hidden state - the NEW hidden state is written
+ * back there; c_prev / c_next f32 [6 n_clips, face, face, H]; h_f32 (optional) an f32 copy of the new hidden state.
+ * x_next != NULL (needs Cin == H): frame t+1 of clip 0 (f32, pixel-major [6 face^2, H]; clip b at + b * clip_stride
+ * elements) is window-normalised with minmax [n_clips, 2] (temporal_model/test_temporal.py:77) into the x half of xh in
+ * the same pass.  model/clstm.py:42-82. */
+int cp360_clstm_step(cp360_ctx* ctx, void* xh, const float* c_prev, float* c_next, float* h_f32, int n_clips, int face,
+                     const float* x_next, const float* minmax, size_t clip_stride, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
