@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 300
+ABI_VERSION = 302
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -44,6 +44,7 @@ SYMBOLS = [
     'cp360_resize_linear_f32', 'cp360_metric_work_bytes', 'cp360_metric_auc_prepare', 'cp360_metric_auc_judd',
     'cp360_metric_auc_borji', 'cp360_metric_cc_sim',
     'cp360_resize_ksize2', 'cp360_resize_coeffs_host2', 'cp360_overlay_colorize', 'cp360_overlay_blend_u8',
+    'cp360_l2first_w3d_bytes', 'cp360_l2first_pack_w3d', 'cp360_l2first_forward',
     'cp360_fold_bn', 'cp360_create', 'cp360_destroy', 'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward',
     'cp360_clstm_load', 'cp360_clstm_workspace_bytes', 'cp360_clstm_step',
 ]
@@ -150,6 +151,10 @@ def lib():
     L.cp360_metric_auc_judd.argtypes = [i, vp, vp, vp]
     L.cp360_metric_auc_borji.argtypes = [i, i, vp, C.c_double, vp, vp, vp]
     L.cp360_metric_cc_sim.argtypes = [vp, vp, i, vp, vp]
+    L.cp360_l2first_w3d_bytes.restype = sz
+    L.cp360_l2first_w3d_bytes.argtypes = [i]
+    L.cp360_l2first_pack_w3d.argtypes = [i, vp, vp, vp, vp, vp, vp]
+    L.cp360_l2first_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.cp360_fold_bn.argtypes = [vp, vp, vp, vp, f, vp, vp, i, vp]
     L.cp360_create.argtypes = [i, C.POINTER(vp)]
     L.cp360_destroy.argtypes = [vp]

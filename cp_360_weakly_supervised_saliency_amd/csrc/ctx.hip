@@ -325,6 +325,13 @@ extern "C" int cp360_resnet_load(cp360_ctx* ctx, int dtype, const cp360_conv_bn*
                     if (!(B.wdf = own.take(cp360_frag_packed_bytes(dtype, 256, 64)))) return CP360_ERR_HIP;
                     if ((rc = cp360_frag_pack_1x1(dtype, pd->weight, fd.scale, B.wdf, 256, 64, 0, st))) return rc;
                 }
+            } else if (h16 && L == 1 && B.has_ds) {          // layer2.0 after its conv1 as one launch (K3f, 56x56 -> 28x28 faces)
+                if (!(B.w2 = own.take(cp360_l2block_packed_bytes(dtype)))) return CP360_ERR_HIP;
+                if ((rc = cp360_l2block_pack_weights(dtype, p2.weight, f2.scale, B.w2, st))) return rc;
+                B.b2 = f2.bias;
+                if (!(B.w3f = own.take(cp360_l2first_w3d_bytes(dtype)))) return CP360_ERR_HIP;
+                if ((rc = cp360_l2first_pack_w3d(dtype, p3.weight, f3.scale, pd->weight, fd.scale, B.w3f, st))) return rc;
+                B.b3 = f3.bias;               // b3 + bd
             } else if (h16 && (L == 1 || L == 2) && !B.has_ds) {
                 const size_t nb = L == 1 ? cp360_l2block_packed_bytes(dtype) : cp360_l3block_packed_bytes(dtype);
                 if (!(B.w2 = own.take(nb))) return CP360_ERR_HIP;
@@ -343,7 +350,7 @@ extern "C" int cp360_resnet_load(cp360_ctx* ctx, int dtype, const cp360_conv_bn*
                 int order = 1;
                 if (L == 0 && b > 0) prev = &R.layer[0][b - 1];
                 else if (L == 1 && b == 0) prev = &R.layer[0][nblk[0] - 1];
-                else if (L == 1 && b >= 2) { prev = &R.layer[1][b - 1]; order = 0; }
+                else if (L == 1 && b >= 1) { prev = &R.layer[1][b - 1]; order = 0; }   // (b == 1: onto layer2.0's fused kernel)
                 if (prev) {
                     if (!(prev->w1f = own.take(cp360_frag_packed_bytes(dtype, planes, inplanes)))) return CP360_ERR_HIP;
                     if ((rc = cp360_frag_pack_1x1(dtype, p1.weight, f1.scale, prev->w1f, planes, inplanes, order, st))) return rc;
@@ -483,9 +490,28 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
         }
     }
     // ---- layer2 / layer3: first block per convolution, identity blocks as fused tails where the kernels exist
+    bool l2_mid1 = false;                                 // layer2.0's kernel also computed layer2.1's conv1
     for (int L = 1; L <= 2; ++L) {
         std::vector<CBlock>& Lr = R.layer[L];
-        CK(bottleneck(Lr[0], face, L == 1 ? mid2 : nullptr));
+        if (L == 1 && h16 && face == 56) {
+            // layer2.0: conv1 (unless layer1's last tail kernel computed it), then ONE launch (K3f)
+            const void* mid = mid2;
+            if (!mid) {
+                CK(run.conv(Lr[0].c1, buf[cur], n_img, face, face, nullptr, 0, other(1), 0, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr));
+                mid = other(1);
+            }
+            // out -> other(3); the chained conv1 of layer2.1 (when that block runs on the fused tail) -> other(2)
+            l2_mid1 = Lr[0].w1f != nullptr;
+            if (!dry) CK(cp360_l2first_forward(dtype, mid, Lr[0].w2, Lr[0].b2, Lr[0].w3f, Lr[0].b3, buf[cur], other(3),
+                                               l2_mid1 ? Lr[0].w1f : nullptr, l2_mid1 ? Lr[0].b1n : nullptr,
+                                               l2_mid1 ? other(2) : nullptr, n_img, face / 2, st));
+            cur = (cur + 3) & 3;                          // x = old other(3); old other(2) = the new other(3)
+            if (l2_mid1 && !dry) {                        // the identity loop expects its mid in other(1): swap the two free roles
+                unsigned char* t = buf[(cur + 3) & 3]; buf[(cur + 3) & 3] = buf[(cur + 1) & 3]; buf[(cur + 1) & 3] = t;
+            }
+        } else {
+            CK(bottleneck(Lr[0], face, L == 1 ? mid2 : nullptr));
+        }
         face /= 2;
         const bool fused = h16 && (L == 1 ? (face == 28 || face == 64) : face == 14);
         if (!fused) {
@@ -493,7 +519,7 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
             continue;
         }
         const bool chain = L == 1 && face == 28;          // the next block's conv1 rides on the tail kernel
-        bool have_mid = false;                            // other(1) holds this block's conv1 output
+        bool have_mid = L == 1 && l2_mid1;                // other(1) holds this block's conv1 output
         for (size_t b = 1; b < Lr.size(); ++b) {
             CBlock& B = Lr[b];
             if (!have_mid)

@@ -33,6 +33,7 @@ FUSE_LAYER3 = True
 FUSE_STEM_POOL = os.environ.get('CP360_FUSE_STEM_POOL', '1') != '0'    # A/B switch: 0 = stem kernel, then max-pool kernel
 LAUNCH_ORDER = int(os.environ.get('CP360_LAUNCH_ORDER', '2'))   # 0: every launch ascending (A/B switch)
 FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
+FUSE_L2_FIRST = True       # layer2.0 after its conv1 as one launch (csrc/lfirst.hip): stride-2 conv2 -> conv3 + downsample
 CHAIN_L1_L2 = True         # layer2.0's conv1 (256 -> 128) chained onto layer1's last tail kernel (csrc/l1block.hip, wide)
 
 
@@ -260,7 +261,23 @@ class ResNet(nn.Module):
         downsample) block stays on the per-convolution path."""
         dt = _DTYPES[self.precision]
         blks = list(self.layer2)
-        x = blks[0].forward_nhwc(x, mid=mid0)          # mid0: conv1 of the first block, from layer1's last tail kernel
+        b0 = blks[0]
+        if (FUSE_L2_FIRST and dt in (torch.float16, torch.bfloat16) and tuple(x.shape[1:]) == (56, 56, 256) and b0.stride == 2
+                and b0.downsample is not None and tuple(b0.conv2.weight.shape) == (128, 128, 3, 3)):
+            # the first block after its conv1 as ONE launch (K3f): stride-2 conv2 -> conv3 + downsample(x) + relu
+            b1 = blks[1]
+            stamp0 = _stamp(b0, (self.precision,)) + _stamp(b1.conv1) + _stamp(b1.bn1)
+            if getattr(self, '_l2f', None) is None or stamp0 != self._l2f_stamp:
+                c = lambda conv, bn: (conv.weight,) + _fold_bn(bn)
+                nx = c(b1.conv1, b1.bn1) if tuple(b1.conv1.weight.shape[:2]) == (128, 512) else None
+                self._l2f = ops.L2First(c(b0.conv2, b0.bn2), c(b0.conv3, b0.bn3), c(b0.downsample[0], b0.downsample[1]), dt,
+                                        self.conv1.weight.device, next_conv1=nx)
+                self._l2f_stamp = stamp0
+            r = self._l2f(b0._plans()['c1'](x) if mid0 is None else mid0, x, chain=FUSE_LAYER2 and FUSE_LAYER2_NEXT)
+            x, mid1 = r if isinstance(r, tuple) else (r, None)     # mid1: layer2.1's conv1 output
+        else:
+            x = b0.forward_nhwc(x, mid=mid0)           # mid0: conv1 of the first block, from layer1's last tail kernel
+            mid1 = None
         if not (FUSE_LAYER2 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] and x.shape[1] in (28, 64)
                 and all(b.downsample is None and b.stride == 1 for b in blks[1:])):
             for blk in blks[1:]:
@@ -275,7 +292,7 @@ class ResNet(nn.Module):
                         for k, b in enumerate(ident)]
             self._l2_stamp = stamp
         chain = FUSE_LAYER2_NEXT and x.shape[1] == 28          # the next block's conv1 rides on the tail (28x28 faces)
-        mid = None
+        mid = mid1
         for k, (blk, tail) in enumerate(zip(blks[1:], self._l2)):
             if mid is None:
                 mid = blk._plans()['c1'](x)

@@ -572,6 +572,51 @@ class L2Block:
         return out
 
 
+class L2First:
+    """K3f (csrc/lfirst.hip): layer2's first Bottleneck after its conv1 as ONE launch - conv2 (CubePad(1) + 3x3 stride 2) +
+    bn2 + relu -> conv3 + bn3 + downsample(x) + relu.  16-bit types, 56x56 -> 28x28 faces.  (weight, bn scale, bn bias) triples."""
+
+    def __init__(self, conv2, conv3, downsample, dtype=torch.float16, device='cuda', next_conv1=None):
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError("L2First runs in fp16 / bf16")
+        self.dtype, self.device = dtype, torch.device(device)
+        L, code = lib(), dtype_code(dtype)
+        f32 = lambda t: None if t is None else t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        (w2, s2, b2), (w3, s3, b3), (wd, sd, bd) = conv2, conv3, downsample
+        if tuple(w2.shape) != (128, 128, 3, 3) or tuple(w3.shape[:2]) != (512, 128) or tuple(wd.shape[:2]) != (512, 256):
+            raise ValueError("L2First is layer2.0's geometry: conv2 128->128 3x3 s2, conv3 128->512, downsample 256->512 s2")
+        self.w2 = torch.empty(L.cp360_l2block_packed_bytes(code), dtype=torch.uint8, device=self.device)
+        check(L.cp360_l2block_pack_weights(code, ptr(f32(w2)), ptr(f32(s2)), ptr(self.w2), stream()))
+        self.b2 = f32(b2)
+        self.w3d = torch.empty(L.cp360_l2first_w3d_bytes(code), dtype=torch.uint8, device=self.device)
+        check(L.cp360_l2first_pack_w3d(code, ptr(f32(w3).reshape(512, 128)), ptr(f32(s3)), ptr(f32(wd).reshape(512, 256)),
+                                       ptr(f32(sd)), ptr(self.w3d), stream()))
+        self.b3d = (f32(b3) + f32(bd)).contiguous()
+        self.w1 = self.b1 = None
+        if next_conv1 is not None:                       # layer2.1's conv1 (512 -> 128) chained onto this launch
+            w1, s1, b1 = next_conv1
+            if tuple(w1.shape[:2]) != (128, 512):
+                raise ValueError("the chained conv1 is 512->128")
+            self.w1 = frag_pack_1x1(w1, s1, dtype, 0, self.device)
+            self.b1 = f32(b1)
+
+    def __call__(self, mid, x, chain=True):
+        """mid [n_img, 56, 56, 128] (conv1 output), x [n_img, 56, 56, 256] (block input) -> out [n_img, 28, 28, 512]
+        (with ``next_conv1`` and chain=True: (out, the next block's conv1 output [n_img, 28, 28, 128]))."""
+        require_gpu(mid, x)
+        n_img = mid.shape[0]
+        _check_buf('mid', mid, self.dtype, (n_img, 56, 56, 128))
+        _check_buf('x', x, self.dtype, (n_img, 56, 56, 256))
+        if mid.shape[3] != 128 or x.shape[3] != 256:
+            raise ValueError("dense NHWC tensors only")
+        out = torch.empty((n_img, 28, 28, 512), dtype=self.dtype, device=mid.device)
+        nxt = torch.empty((n_img, 28, 28, 128), dtype=self.dtype, device=mid.device) if (self.w1 is not None and chain) else None
+        check(lib().cp360_l2first_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3d),
+                                          ptr(self.b3d), ptr(x), ptr(out), ptr(self.w1) if nxt is not None else None,
+                                          ptr(self.b1) if nxt is not None else None, ptr(nxt), n_img, 28, stream()))
+        return out if nxt is None else (out, nxt)
+
+
 class L3Block:
     """K3e at layer3's geometry (csrc/l2block.hip, C = 256): the tail of a layer3 identity Bottleneck as ONE launch -
     conv2 + bn2 + relu -> conv3 + bn3 + residual + relu.  16-bit types, 14x14 faces.  (weight, bn scale, bn bias) triples."""

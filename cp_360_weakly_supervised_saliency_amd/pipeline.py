@@ -90,7 +90,7 @@ class SaliencyEngine:
                 chunk = self.resize(chunk)
             # K1 writes the CubePad(3)-padded faces directly (one pass instead of project + pad)
             x4 = self.e2c.to_cube_batch(chunk, out_dtype=self.dtype, layout='nhwc4p3')
-            cam_device(x4, self.resnet, out=cam_flat[lo:hi], padded=True)     # CAM conv writes the clip buffer directly
+            cam_device(x4, self.resnet, out=cam_flat[lo:hi], padded=True, want_feat=False)     # CAM conv writes the clip buffer directly
         return self.cam
 
     def temporal_stage(self, cam=None):

@@ -12,7 +12,7 @@ import torch
 from .. import _lib, ops, stage_ctx
 
 
-def cam_device(input_cubemap_nhwc4, model, out=None, padded=False):
+def cam_device(input_cubemap_nhwc4, model, out=None, padded=False, want_feat=True):
     """Fused device path: normalised cube faces [6N, H, W, 4] (NHWC4, the output of
     ``Equi2Cube.to_cube_batch``) -> (cube_score f32 [6N, h, w, 1000] NHWC,
     layer4 features [6N, h, w, 2048] NHWC in the model's compute dtype)."""
@@ -23,7 +23,7 @@ def cam_device(input_cubemap_nhwc4, model, out=None, padded=False):
         if stage is None:
             stage = model.__dict__['_stage'] = stage_ctx.ResnetStage(model)
         xp = input_cubemap_nhwc4 if padded else ops.cubepad_nhwc(input_cubemap_nhwc4, 3)
-        return stage.forward(xp, cam_out=None if out is None else out.view(-1))
+        return stage.forward(xp, cam_out=None if out is None else out.view(-1), want_feat=want_feat)
     feat = model.features_nhwc(input_cubemap_nhwc4, padded)      # padded: the faces already carry their CubePad(3) ring
     cam = model.cam_conv()
     n6, h, w, _ = feat.shape

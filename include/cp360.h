@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 300
+#define CP360_VERSION 302
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -328,6 +328,22 @@ int cp360_l2block_forward_next(int dtype, const void* mid, const void* w2_packed
                                const void* w3_frags, const float* bias3, const void* residual, void* out,
                                const void* w1_frags, const float* bias1, void* out_next, int n_img, int face,
                                void* stream);
+
+/* ------------------------------------------------------------------ K3f: layer2's FIRST Bottleneck after its conv1 (csrc/lfirst.hip)
+ * conv2 (CubePad(1) + 3x3 STRIDE 2, 128 -> 128) + bn2 + relu -> conv3 (1x1, 128 -> 512) + bn3 + downsample(x) (1x1 stride 2,
+ * 256 -> 512, + bn) + relu of layer2.0 (model/resnet_cubic.py:85-106,145-161) in ONE kernel, cube size 224 (56x56 -> 28x28
+ * faces: face_out = 28, anything else CP360_ERR_UNSUPPORTED), CP360_BF16 / CP360_F16.
+ *   mid [n_img, 56, 56, 128] (the block's conv1 output), w2_packed = cp360_l2block_pack_weights(w2 [128,128,3,3]), bias2 f32 [128],
+ *   w3d_frags = cp360_l2first_pack_w3d(w3 [512,128] x scale3, wd [512,256] x scaled): fragments of the K = 384 filter
+ *   [W3 | Wd], bias3d f32 [512] = b3 + bd, x [n_img, 56, 56, 256] (the block input), out [n_img, 28, 28, 512]. */
+size_t cp360_l2first_w3d_bytes(int dtype);
+int cp360_l2first_pack_w3d(int dtype, const float* w3, const float* scale3, const float* wd, const float* scaled, void* packed,
+                           void* stream);
+/* w1_frags = cp360_frag_pack_1x1(w1 [128, 512], order 0) + bias1 f32 [128] (or NULL) + out_next [n_img, 28, 28, 128]: the same
+ * launch also computes the NEXT block's conv1 (layer2.1: 1x1, 512 -> 128) + bn1 + relu from the output pieces; all NULL: not. */
+int cp360_l2first_forward(int dtype, const void* mid, const void* w2_packed, const float* bias2, const void* w3d_frags,
+                          const float* bias3d, const void* x, void* out, const void* w1_frags, const float* bias1,
+                          void* out_next, int n_img, int face_out, void* stream);
 
 /* The same kernel at layer3's geometry (csrc/l2block.hip, C = 256): conv2 (CubePad(1) + 3x3, 256 -> 256) + bn2 + relu ->
  * conv3 (1x1, 256 -> 1024) + bn3 + identity residual + relu of layer3's identity Bottlenecks at cube size 224

@@ -377,6 +377,45 @@ def test_layer1_last_tail_chains_layer2_conv1(prec, face):
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n_img', [6, 12])
+def test_layer2_first_block_fused_kernel(prec, n_img):
+    """K3f (csrc/lfirst.hip): layer2.0 after its conv1 as ONE launch - CubePad(1) + conv3x3 stride 2 + bn2 + relu ->
+    conv3 + bn3 + downsample(x) + relu (resnet_cubic.py:85-106,145-161) - vs (a) the per-convolution path (generic stride-2
+    conv + second-source conv3) on the same rounded operands and (b) torch-CPU ``_bottleneck`` in f32."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    from oracle import o_resnet
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4650 + n_img, (n_img, 56, 56, 256), 0.0, 1.0))).to(DEV).to(dt)
+    b0 = m.layer2[0]
+    mid = b0._plans()['c1'](x)
+    m.layer2_nhwc(x)                                  # builds m._l2f
+    got_t = m._l2f(mid, x, chain=False)
+    got = got_t.float().cpu().numpy()
+    sep = b0.forward_nhwc(x, mid=mid).float().cpu().numpy()
+    assert got.shape == (n_img, 28, 28, 512)
+    assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    # the variant that also computes layer2.1's conv1 (512 -> 128) from the output pieces: same out bit for bit, and
+    # mid1 == the per-convolution conv1 on that rounded out
+    out_c, mid1 = m._l2f(mid, x, chain=True)
+    assert torch.equal(out_c, got_t) and tuple(mid1.shape) == (n_img, 28, 28, 128)
+    c1 = m.layer2[1]._plans()['c1'](out_c)
+    assert rel_err(mid1.float().cpu().numpy(), c1.float().cpu().numpy()) <= _TOL[prec]
+    # the whole layer with / without the fused first block
+    full = m.layer2_nhwc(x).float().cpu().numpy()
+    rc.FUSE_L2_FIRST = False
+    try:
+        full_sep = m.layer2_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_L2_FIRST = True
+    assert rel_err(full, full_sep) <= _TOL[prec], rel_err(full, full_sep)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    with torch.no_grad():
+        want = o_resnet._bottleneck(x.float().cpu().permute(0, 3, 1, 2).contiguous(), sdt, 'layer2.0', 2, True)
+    assert rel_err(got, want.permute(0, 2, 3, 1).numpy()) <= 2 * _TOL[prec]
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 def test_layer2_fused_tail_kernel_cube512_faces(prec):
     """K3e at 64x64 faces (cube 512, BASELINE config C5): bands of two output rows (128 pixels = 8 pixel blocks)."""
     from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
