@@ -65,7 +65,8 @@ struct OpMax { __device__ double operator()(double a, double b) const { return a
 
 // Workspace layout (doubles): [0] n_fix, [1] unused, then S [n] (normalised saliency, f64), Sth [n] (values at
 // fixated pixels, compacted), pts [2 * (n + 2)] (fp, tp by rank).
-// mode 0 (AUC_Judd): S = sal (+ jitter); S = (S - min) / (max - min)                                     :104-116
+// mode 0 (AUC_Judd): S = sal (+ jitter); S = (S - min) / (max - min) - in float64 with the (float64) jitter, in float32
+//   without it, as numpy's type promotion does                                                          :104-116
 // mode 1 (AUC_Borji): S[S > mean + 2 std] = 1 (float32), then the same normalisation in float32         :37-40
 __global__ __launch_bounds__(1024) void auc_prepare_kernel(const float* __restrict__ sal, const float* __restrict__ fix,
                                                            const double* __restrict__ jitter, int n, int mode,
@@ -101,6 +102,15 @@ __global__ __launch_bounds__(1024) void auc_prepare_kernel(const float* __restri
             const float v = sal[i] > sthr ? 1.0f : sal[i];
             S[i] = (double)((v - fmn) / (fmx - fmn));
         }
+    } else if (!jitter) {
+        // jitter=False: the reference normalises the float32 map in float32 (no float64 randn term promotes it, :104-116)
+        double mn = 1e300, mx = -1e300;
+        for (int i = tid; i < n; i += 1024) {
+            mn = fmin(mn, (double)sal[i]);
+            mx = fmax(mx, (double)sal[i]);
+        }
+        const float fmn = (float)block_reduce(mn, OpMin(), sm), fmx = (float)block_reduce(mx, OpMax(), sm);
+        for (int i = tid; i < n; i += 1024) S[i] = (double)((sal[i] - fmn) / (fmx - fmn));
     } else {
         double mn = 1e300, mx = -1e300;
         for (int i = tid; i < n; i += 1024) {

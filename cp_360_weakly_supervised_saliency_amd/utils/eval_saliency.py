@@ -8,6 +8,11 @@ sits in the ``dst`` slot: default bilinear).  Random draws come from numpy's GLO
 the reference draws them (``np.random.randn`` for AUC_Judd's jitter, ``np.random.randint`` for AUC_Borji's
 splits), so ``np.random.seed(s)`` in front of a call gives the reference's value for the same seed.
 No CPU fallback: the functions need the HIP library and a GPU.
+
+Types: the maps the path produces are float32 and are resized in float32 (cv2.resize keeps the input type); a float64
+input (e.g. a ground-truth map stored as float64) is cast to float32 first - the only consumer of its values is the
+``F > mean(F) + 2 std(F)`` fixation threshold, evaluated in float64 from those float32 values.  AUC_Judd normalises in
+float64 with jitter (the float64 ``randn`` term promotes the map, as in numpy) and in float32 with ``jitter=False``.
 """
 import ctypes as C
 

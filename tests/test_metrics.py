@@ -54,6 +54,20 @@ def test_oracle_metrics_match_reference_goldens(golden_dir):
 
 
 @pytest.mark.gpu
+def test_hip_auc_judd_without_jitter_normalises_in_float32(golden_dir):
+    """AUC_Judd(jitter=False), utils/eval_saliency.py:104-116 without the float64 randn term: the float32 map is
+    normalised in float32 (numpy type promotion) - HIP == the oracle, whose numpy arithmetic has exactly that typing,
+    including maps with many exact ties (quantised values), where the last bit of the normalisation decides ranks."""
+    from tests.golden.make_golden import METRIC_CASES, metric_inputs
+    from cp_360_weakly_supervised_saliency_amd.utils import eval_saliency as ev
+    for k in range(len(METRIC_CASES)):
+        sal, gt = metric_inputs(k)
+        for s in (sal, np.round(sal * 37.0).astype(np.float32) / np.float32(37.0) * np.float32(1.7)):
+            want = o_metrics.auc_judd(s, gt, jitter=False)
+            assert abs(ev.AUC_Judd(s, gt, jitter=False) - want) <= 1e-12, k
+
+
+@pytest.mark.gpu
 def test_hip_metrics_match_reference_goldens_and_oracle(golden_dir):
     """K8 (csrc/metrics.hip) behind the reference's names: the seeded cases of tests/golden/metrics.npz
     (values computed by the reference's own eval_saliency.py) and the oracle on a second set of maps."""
