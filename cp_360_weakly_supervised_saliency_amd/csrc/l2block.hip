@@ -213,27 +213,42 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
 #pragma unroll
             for (int j = 0; j < PB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         constexpr int JG = HC > 1 ? 4 : PB;                    // (two channel halves: the kept t pieces leave room for 4 B fragments at a time)
+        constexpr int NG = (PB + JG - 1) / JG;                 // groups per k-block (1 / 2): KK * NG <= 4 groups per step
+        static_assert(KK * NG <= 4, "CP360_BT_STEP unrolls four groups");
         if (hc == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch DMAs (and the first fragments)
             __syncthreads();
         }
-#define CP360_BT_STEP(S, SLOT, POFF, KOFF, SUB)                                                                    \
+        // B fragments are read one GROUP ahead of the MFMAs that use them (two register sets; a group = up to JG pixel
+        // blocks of one k-block): the LDS latency of a group's reads hides under the previous group's MFMAs instead of in
+        // front of its own (round 3, measured first on lfirst.hip: -8 %).  The first group of a step is read in the step.
+#define CP360_BT_READ(DST, GI, POFF, KOFF, SUB)                                                                \
+        {                                                                                                     \
+            constexpr int kk_ = (GI) / NG, j0_ = ((GI) % NG) * JG;                                            \
+            _Pragma("unroll") for (int u = 0; u < JG; ++u)                                                    \
+                if (j0_ + u < PB) {                                                                           \
+                    const int p = pbase[j0_ + u] + (POFF);                                                    \
+                    DST[u] = *reinterpret_cast<const u32x4*>(patch + p * PXB + (((((SUB) * KK + kk_) * 4 + lchunk) ^ ((lrow + (KOFF)) & 15)) << 4)); \
+                }                                                                                             \
+        }
+#define CP360_BT_GROUP(GI, S, SLOT, POFF, KOFF, SUB)                                                           \
+        if constexpr ((GI) < KK * NG) {                                                                       \
+            constexpr int kk_ = (GI) / NG, j0_ = ((GI) % NG) * JG;                                            \
+            if constexpr ((GI) + 1 < KK * NG) CP360_BT_READ(bq[((GI) + 1) & 1], (GI) + 1, POFF, KOFF, SUB)    \
+            _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                                   \
+                _Pragma("unroll") for (int u = 0; u < JG; ++u)                                                \
+                    if (j0_ + u < PB) mma<T>(acc[i][j0_ + u], aq[(SLOT) % (DEPTH + 1)][i][kk_], bq[(GI) & 1][u]); \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }
+#define CP360_BT_STEP(S, SLOT, POFF, KOFF, SUB)                                                                \
         {                                                                                                     \
             if ((S) + DEPTH < STEPS) load_a((S) + DEPTH, aq[((SLOT) + DEPTH) % (DEPTH + 1)]);                 \
-            _Pragma("unroll") for (int kk = 0; kk < KK; ++kk) {                                               \
-                _Pragma("unroll") for (int j0 = 0; j0 < PB; j0 += JG) {                                       \
-                    u32x4 b[JG];                                                                              \
-                    _Pragma("unroll") for (int u = 0; u < JG; ++u)                                            \
-                        if (j0 + u < PB) {                                                                    \
-                            const int p = pbase[j0 + u] + (POFF);                                             \
-                            b[u] = *reinterpret_cast<const u32x4*>(patch + p * PXB + (((((SUB) * KK + kk) * 4 + lchunk) ^ ((lrow + (KOFF)) & 15)) << 4)); \
-                        }                                                                                     \
-                    _Pragma("unroll") for (int i = 0; i < RBW; ++i)                                           \
-                        _Pragma("unroll") for (int u = 0; u < JG; ++u)                                        \
-                            if (j0 + u < PB) mma<T>(acc[i][j0 + u], aq[(SLOT) % (DEPTH + 1)][i][kk], b[u]);   \
-                    __builtin_amdgcn_sched_barrier(0);                                                        \
-                }                                                                                             \
-            }                                                                                                 \
+            u32x4 bq[2][JG];                                                                                  \
+            CP360_BT_READ(bq[0], 0, POFF, KOFF, SUB)                                                          \
+            CP360_BT_GROUP(0, S, SLOT, POFF, KOFF, SUB)                                                       \
+            CP360_BT_GROUP(1, S, SLOT, POFF, KOFF, SUB)                                                       \
+            CP360_BT_GROUP(2, S, SLOT, POFF, KOFF, SUB)                                                       \
+            CP360_BT_GROUP(3, S, SLOT, POFF, KOFF, SUB)                                                       \
         }
         if constexpr (SPT % (DEPTH + 1) == 0) {                // layer3: 4 steps per tap, the tap loop stays rolled
 #pragma unroll 1
@@ -252,6 +267,8 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
             }
         }
 #undef CP360_BT_STEP
+#undef CP360_BT_GROUP
+#undef CP360_BT_READ
         // ---- stage 2: t = relu(conv2 + b2), rounded once -> the band's t tile (in place of its patch, once every wave
         // is done with the patch: after the LAST channel half)
         if (hc == HC - 1) __syncthreads();
