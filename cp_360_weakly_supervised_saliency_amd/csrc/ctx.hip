@@ -513,7 +513,7 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
             CK(bottleneck(Lr[0], face, L == 1 ? mid2 : nullptr));
         }
         face /= 2;
-        const bool fused = h16 && (L == 1 ? (face == 28 || face == 64) : face == 14);
+        const bool fused = h16 && (L == 1 ? (face == 28 || face == 64) : (face == 14 || face == 32));
         if (!fused) {
             for (size_t b = 1; b < Lr.size(); ++b) CK(bottleneck(Lr[b], face, nullptr));
             continue;

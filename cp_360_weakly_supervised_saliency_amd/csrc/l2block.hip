@@ -39,7 +39,7 @@ constexpr int W_STEP = 16 * 1024;                            // conv2 weights pe
 // Channels C (mid) -> CO = 4 C (out), face size N, BAND output rows per band (4 waves), NB bands per workgroup.
 //   layer2 (C = 128): 28x28 faces -> 4 rows = 112 pixels = 7 pixel blocks; 64x64 faces (cube 512, BASELINE config C5) ->
 //     2 rows = 128 pixels = 8 blocks.  A wave owns 32 conv2 channels (2 row blocks); a step = half a tap (K = 64).
-//   layer3 (C = 256): 14x14 faces -> 7 rows = 98 pixels in 7 blocks (the last 14 pixel slots are padding: they read
+//   layer3 (C = 256): 32x32 faces (cube 512) -> 2 rows = 64 pixels = 4 blocks; 14x14 faces -> 7 rows = 98 pixels in 7 blocks (the last 14 pixel slots are padding: they read
 //     pixel 97 again and store nothing).  A wave owns 2 x 32 conv2 channels, computed one after the other (HC = 2
 //     channel halves: the accumulators of 64 channels x 7 blocks do not fit next to the fragment prefetch); the first
 //     half's rounded t pieces wait in registers, because the t tile replaces the patch the second half still reads;
@@ -520,7 +520,7 @@ static int bt_launch(int layer, int dtype, const void* mid, const void* w2_packe
     if (!mid || !w2_packed || !w3_frags || !bias3 || !residual || !out) return CP360_ERR_NULL;
     if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
     if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
-    if (layer == 2 ? (face != 28 && face != 64) : face != 14) return CP360_ERR_UNSUPPORTED;
+    if (layer == 2 ? (face != 28 && face != 64) : (face != 14 && face != 32)) return CP360_ERR_UNSUPPORTED;
     if (out_next && (layer != 2 || face != 28)) return CP360_ERR_UNSUPPORTED;   // the chained conv1: layer2, 28x28 faces
     const int co = layer == 2 ? 512 : 1024;
     if ((long long)n_img * face * face * co >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
@@ -533,7 +533,8 @@ static int bt_launch(int layer, int dtype, const void* mid, const void* w2_packe
                        (const TT*)w1_frags, bias1, (TT*)out_next, cp360_launch_reverse())
 #define CP360_L2B_T(TT)                                                  \
     {                                                                    \
-        if (layer == 3) CP360_L2B(TT, 256, 1, 14, 7, false);             \
+        if (layer == 3 && face == 32) CP360_L2B(TT, 256, 1, 32, 2, false);  \
+        else if (layer == 3) CP360_L2B(TT, 256, 1, 14, 7, false);        \
         else if (out_next) CP360_L2B(TT, 128, 1, 28, 4, true);           \
         else if (face == 64) CP360_L2B(TT, 128, 1, 64, 2, false);        \
         else if (nb == 2) CP360_L2B(TT, 128, 2, 28, 4, false);           \

@@ -309,7 +309,7 @@ class ResNet(nn.Module):
         dt = _DTYPES[self.precision]
         blks = list(self.layer3)
         x = blks[0].forward_nhwc(x)
-        if not (FUSE_LAYER3 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] == 14
+        if not (FUSE_LAYER3 and dt in (torch.float16, torch.bfloat16) and x.shape[1] == x.shape[2] and x.shape[1] in (14, 32)
                 and all(b.downsample is None and b.stride == 1 for b in blks[1:])):
             for blk in blks[1:]:
                 x = blk.forward_nhwc(x)

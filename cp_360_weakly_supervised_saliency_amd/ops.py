@@ -638,11 +638,11 @@ class L3Block:
         self.b3 = f32(b3)
 
     def __call__(self, mid, residual):
-        """mid [n_img, 14, 14, 256], residual [n_img, 14, 14, 1024] -> out [n_img, 14, 14, 1024]."""
+        """mid [n_img, n, n, 256], residual [n_img, n, n, 1024] -> out [n_img, n, n, 1024]; n = 14 (cube 224) or 32 (cube 512)."""
         require_gpu(mid, residual)
         n_img, n = mid.shape[0], mid.shape[1]
-        if n != 14:
-            raise ValueError("L3Block handles 14x14 faces")
+        if n not in (14, 32):
+            raise ValueError("L3Block handles 14x14 and 32x32 faces")
         _check_buf('mid', mid, self.dtype, (n_img, n, n, 256))
         _check_buf('residual', residual, self.dtype, (n_img, n, n, 1024))
         if mid.shape[3] != 256 or residual.shape[3] != 1024:

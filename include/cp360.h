@@ -347,7 +347,7 @@ int cp360_l2first_forward(int dtype, const void* mid, const void* w2_packed, con
 
 /* The same kernel at layer3's geometry (csrc/l2block.hip, C = 256): conv2 (CubePad(1) + 3x3, 256 -> 256) + bn2 + relu ->
  * conv3 (1x1, 256 -> 1024) + bn3 + identity residual + relu of layer3's identity Bottlenecks at cube size 224
- * (14x14 faces: `face` = 14, anything else CP360_ERR_UNSUPPORTED).
+ * (14x14 faces: `face` = 14) or 512 (32x32 faces, bands of two rows: `face` = 32); anything else CP360_ERR_UNSUPPORTED.
  *   mid [n_img, 14, 14, 256], w2_packed = cp360_l3block_pack_weights(w2 [256,256,3,3]), bias2 f32 [256],
  *   w3_frags = cp360_frag_pack_1x1(w3 [1024, 256], order 0), bias3 f32 [1024], residual / out [n_img, 14, 14, 1024]. */
 size_t cp360_l3block_packed_bytes(int dtype);

@@ -503,6 +503,32 @@ def test_layer3_fused_tail_kernel(prec, n_img):
     assert rel_err(got, want) <= 6 * _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_layer3_fused_tail_kernel_cube512_faces(prec):
+    """K3e at layer3's geometry on 32x32 faces (cube 512, BASELINE config C5): bands of two rows (64 pixels = 4 pixel
+    blocks), vs the per-convolution path and vs torch-CPU (resnet_cubic.py:85-106)."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    from oracle import o_resnet
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4950, (6, 64, 64, 512), 0.0, 1.0))).to(DEV).to(dt)
+    got = m.layer3_nhwc(x).float().cpu().numpy()
+    rc.FUSE_LAYER3 = False
+    try:
+        sep = m.layer3_nhwc(x).float().cpu().numpy()
+    finally:
+        rc.FUSE_LAYER3 = True
+    assert got.shape == (6, 32, 32, 1024)
+    assert rel_err(got, sep) <= _TOL[prec], rel_err(got, sep)
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    xc = x.float().cpu().permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        for b in range(6):
+            xc = o_resnet._bottleneck(xc, sdt, 'layer3.%d' % b, 2 if b == 0 else 1, b == 0)
+        want = xc.permute(0, 2, 3, 1).numpy()
+    assert rel_err(got, want) <= 6 * _TOL[prec], rel_err(got, want)
+
+
 @pytest.mark.parametrize('tile_px', [128, 256, 304])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('splits', [1, 3])
