@@ -44,6 +44,17 @@ __global__ void sub_scalar_kernel(const float* __restrict__ x, float s, float* _
 int es_of(int dtype) { return dtype == CP360_F32 ? 4 : 2; }
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// The context's allocations and launches belong to ITS device, whatever device the calling thread has current
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct Owned {                                   // device allocations a context owns
     std::vector<void*> ptrs;
     void* take(size_t bytes) {
@@ -219,6 +230,7 @@ extern "C" int cp360_create(int device, cp360_ctx** out) {
 
 extern "C" void cp360_destroy(cp360_ctx* ctx) {
     if (!ctx) return;
+    DeviceGuard guard(ctx->device);
     ctx->own_resnet.release();
     ctx->own_clstm.release();
     delete ctx;
@@ -253,6 +265,8 @@ extern "C" int cp360_resnet_load(cp360_ctx* ctx, int dtype, const cp360_conv_bn*
     if (!ctx || !convs || !fc_weight) return CP360_ERR_NULL;
     if (dtype != CP360_F32 && dtype != CP360_BF16 && dtype != CP360_F16) return CP360_ERR_BAD_DTYPE;
     if (n_convs != 53 || num_classes <= 0 || num_classes % 4 != 0) return CP360_ERR_BAD_SHAPE;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CP360_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     ctx->own_resnet.release();
     ctx->rn = CResnet();
@@ -569,6 +583,8 @@ extern "C" size_t cp360_resnet_workspace_bytes(cp360_ctx* ctx, int n_img, int cu
 extern "C" int cp360_resnet_forward(cp360_ctx* ctx, const void* faces_p3, int n_img, int cube_dim, float* cam_out,
                                     void* feat_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx) return CP360_ERR_NULL;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CP360_ERR_HIP;
     ResnetWs w;
     int rc = resnet_run(ctx, true, nullptr, n_img, cube_dim, nullptr, nullptr, nullptr, 0, nullptr, &w);
     if (rc) return rc;
@@ -582,6 +598,8 @@ extern "C" int cp360_clstm_load(cp360_ctx* ctx, int dtype, const float* w1, cons
     if (!ctx || !w1 || !b1 || !w2 || !b2 || !wg || !bg) return CP360_ERR_NULL;
     if (dtype != CP360_F32 && dtype != CP360_BF16 && dtype != CP360_F16) return CP360_ERR_BAD_DTYPE;
     if (input_size <= 0 || hidden_size <= 0 || face <= 0 || hidden_size % 4 != 0) return CP360_ERR_BAD_SHAPE;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CP360_ERR_HIP;
     hipStream_t st = (hipStream_t)stream;
     ctx->own_clstm.release();
     ctx->cl = CClstm();
@@ -670,6 +688,8 @@ extern "C" int cp360_clstm_step(cp360_ctx* ctx, void* xh, const float* c_prev, f
                                 size_t workspace_bytes, void* stream) {
     if (!ctx) return CP360_ERR_NULL;
     if (x_next && (!minmax || ctx->cl.cin != ctx->cl.ch)) return CP360_ERR_BAD_SHAPE;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CP360_ERR_HIP;
     ClstmWs w;
     int rc = clstm_run(ctx, true, nullptr, nullptr, nullptr, nullptr, n_clips, face, nullptr, nullptr, 0, nullptr, 0, nullptr, &w);
     if (rc) return rc;
