@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 302
+ABI_VERSION = 303
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -47,6 +47,7 @@ SYMBOLS = [
     'cp360_l2first_w3d_bytes', 'cp360_l2first_pack_w3d', 'cp360_l2first_forward',
     'cp360_fold_bn', 'cp360_create', 'cp360_destroy', 'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward',
     'cp360_clstm_load', 'cp360_clstm_workspace_bytes', 'cp360_clstm_step',
+    'cp360_conv_finish_add', 'cp360_window_normalize_frames', 'cp360_clstm_window_workspace_bytes', 'cp360_clstm_window',
 ]
 
 
@@ -167,6 +168,11 @@ def lib():
     L.cp360_clstm_workspace_bytes.restype = sz
     L.cp360_clstm_workspace_bytes.argtypes = [vp, i, i]
     L.cp360_clstm_step.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, sz, vp, sz, vp]
+    L.cp360_conv_finish_add.argtypes = [pd, vp, vp, vp, vp, vp, vp]
+    L.cp360_window_normalize_frames.argtypes = [vp, vp, vp, i, i, i, i, i, sz, vp]
+    L.cp360_clstm_window_workspace_bytes.restype = sz
+    L.cp360_clstm_window_workspace_bytes.argtypes = [vp, i, i, i]
+    L.cp360_clstm_window.argtypes = [vp, vp, sz, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):

@@ -1496,7 +1496,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restrict__ partial, int splits,
                                                           const float* __restrict__ bias, const T* __restrict__ res,
                                                           int ld_res, T* __restrict__ out, int ld_out, int out_coff,
-                                                          int M, int c_out, int relu, int slab_rows) {
+                                                          int M, int c_out, int relu, int slab_rows,
+                                                          const float* __restrict__ extra) {
     const int q = c_out >> 2;
     const long long total = (long long)M * q;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -1506,6 +1507,10 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(const float* __restric
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         for (int s = 0; s < splits; ++s) {
             const float4 t = *reinterpret_cast<const float4*>(partial + ((size_t)s * M + m) * c_out + nc);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (extra) {     // one more f32 addend in the slabs' column order (cp360_conv_finish_add)
+            const float4 t = *reinterpret_cast<const float4*>(extra + (size_t)m * c_out + nc);
             v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
         }
         if (bias) {
@@ -2000,6 +2005,11 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
 
 extern "C" int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const float* bias,
                                  const void* residual, void* out, void* stream) {
+    return cp360_conv_finish_add(d, partial, nullptr, bias, residual, out, stream);
+}
+
+extern "C" int cp360_conv_finish_add(const cp360_conv_desc* d, const float* partial, const float* extra, const float* bias,
+                                     const void* residual, void* out, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!partial || !out) return CP360_ERR_NULL;
@@ -2011,15 +2021,15 @@ extern "C" int cp360_conv_finish(const cp360_conv_desc* d, const float* partial,
     if (d->dtype == CP360_F32)
         hipLaunchKernelGGL((conv_finish_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, partial, d->splits,
                            bias, (const float*)residual, d->ld_res, (float*)out, d->ld_out, d->out_coff, M, d->c_out,
-                           d->relu, d->slab_rows);
+                           d->relu, d->slab_rows, extra);
     else if (d->dtype == CP360_F16)
         hipLaunchKernelGGL((conv_finish_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
                            d->splits, bias, (const f16_raw*)residual, d->ld_res, (f16_raw*)out, d->ld_out,
-                           d->out_coff, M, d->c_out, d->relu, d->slab_rows);
+                           d->out_coff, M, d->c_out, d->relu, d->slab_rows, extra);
     else
         hipLaunchKernelGGL((conv_finish_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, partial,
                            d->splits, bias, (const bf16_raw*)residual, d->ld_res, (bf16_raw*)out, d->ld_out,
-                           d->out_coff, M, d->c_out, d->relu, d->slab_rows);
+                           d->out_coff, M, d->c_out, d->relu, d->slab_rows, extra);
     CP360_CHECK_HIP();
     return CP360_OK;
 }

@@ -12,6 +12,7 @@
 // with exactly the descriptors the Python planning produces, so both paths give the same bits (tests/test_ctx.py).
 #include "common.h"
 #include <new>
+#include <stdlib.h>
 #include <vector>
 
 namespace {
@@ -141,6 +142,8 @@ struct Run {
     hipStream_t st = nullptr;
     int dtype = 0;
 
+    const float* finish_extra = nullptr;         // one more f32 addend for the NEXT split-K finish (consumed by it)
+
     int conv(const CConv& c, const void* in, int n_img, int h, int w, const void* residual, int ld_res, void* out,
              int ld_out, int out_coff, const void* x2, int h2, int w2, int ps2, bool raw, bool raw_slab_rows,
              float* raw_dst, int force_splits, int* splits_out) {
@@ -148,12 +151,13 @@ struct Run {
         const int cr = clip_geometry(c, n_img, h, w) ? 1 : 0;
         fill_desc(c, dtype, n_img, h, w, 1, ld_out, out_coff, ld_res, cr, 0, h2, w2, ps2, &d);
         const int splits = force_splits > 0 ? force_splits : cp360_conv_suggest_splits(&d);
-        const int sr = (c.c_out % 32 == 0 && ((splits > 1 && !raw) || (raw && raw_slab_rows))) ? 1 : 0;
+        const bool extra = finish_extra != nullptr && !raw;          // the sums go through cp360_conv_finish_add even at splits = 1
+        const int sr = (c.c_out % 32 == 0 && (((splits > 1 || extra) && !raw) || (raw && raw_slab_rows))) ? 1 : 0;
         d.splits = splits;
         d.slab_rows = sr;
         if (splits_out) *splits_out = splits;
         const size_t M = (size_t)n_img * d.h_out * d.w_out;
-        const bool to_partial = raw || splits > 1;
+        const bool to_partial = raw || splits > 1 || extra;
         if (to_partial && !raw_dst) {
             const size_t need = (size_t)splits * M * c.c_out * sizeof(float);
             if (need > partial_need) partial_need = need;
@@ -166,7 +170,9 @@ struct Run {
             float* dst = raw_dst ? raw_dst : partial;
             int rc = cp360_conv_forward2(&d, in, x2, pk, nullptr, nullptr, nullptr, dst, st);
             if (rc || raw) return rc;
-            return cp360_conv_finish(&d, dst, c.bias, residual, out, st);
+            const float* ex = finish_extra;
+            finish_extra = nullptr;
+            return cp360_conv_finish_add(&d, dst, ex, c.bias, residual, out, st);
         }
         return cp360_conv_forward2(&d, in, x2, pk, c.bias, residual, out, nullptr, st);
     }
@@ -195,6 +201,8 @@ struct CClstm {
     bool loaded = false;
     int dtype = 0, cin = 0, ch = 0;
     CConv c1, c2, g;
+    CConv c1x, c1h;                              // Conv1 split into its x / h input halves (cp360_clstm_window, batched x half)
+    bool split_ok = false;
     float* gbias = nullptr;
 };
 
@@ -622,6 +630,27 @@ extern "C" int cp360_clstm_load(cp360_ctx* ctx, int dtype, const float* w1, cons
     if ((rc = pack_conv(own, Cl.c1, dtype, w1, nullptr, nullptr, nullptr, !clip, clip, st))) return rc;
     if ((rc = pack_conv(own, Cl.c2, dtype, w2, nullptr, nullptr, nullptr, !clip, clip, st))) return rc;
     if ((rc = pack_conv(own, Cl.g, dtype, wg, nullptr, nullptr, nullptr, !clip, clip, st))) return rc;
+    // Conv1's x / h halves as convolutions of their own (the batched x half of cp360_clstm_window): contiguous f32 copies
+    // of w1[:, :Cin] and w1[:, Cin:], packed, then dropped
+    if (clip && input_size == hidden_size && input_size % 8 == 0) {
+        set_geom(Cl.c1x, c4, input_size, 3, 1, 1, 0);
+        set_geom(Cl.c1h, c4, hidden_size, 3, 1, 1, 1);
+        Cl.c1h.pix_stride = input_size + hidden_size;            // reads the h half of the fused [x | h] buffer in place
+        Cl.c1h.bias = Cl.c1.bias;
+        float* tmp = nullptr;
+        const size_t half = (size_t)input_size * 9 * sizeof(float), full = (size_t)(input_size + hidden_size) * 9 * sizeof(float);
+        if (hipMalloc((void**)&tmp, (size_t)c4 * half) != hipSuccess) return CP360_ERR_HIP;
+        rc = CP360_OK;
+        for (int part = 0; part < 2 && !rc; ++part) {
+            if (hipMemcpy2DAsync(tmp, half, (const char*)w1 + (part ? half : 0), full, half, c4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                rc = CP360_ERR_HIP;
+            if (!rc) rc = pack_conv(own, part ? Cl.c1h : Cl.c1x, dtype, tmp, nullptr, nullptr, nullptr, false, true, st);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = CP360_ERR_HIP;
+        (void)hipFree(tmp);
+        if (rc) return rc;
+        Cl.split_ok = true;
+    }
     CP360_CHECK_HIP();
     Cl.loaded = true;
     return CP360_OK;
@@ -695,4 +724,116 @@ extern "C" int cp360_clstm_step(cp360_ctx* ctx, void* xh, const float* c_prev, f
     if (rc) return rc;
     return clstm_run(ctx, false, xh, c_prev, c_next, h_f32, n_clips, face, x_next, minmax, clip_stride, (unsigned char*)workspace,
                      workspace_bytes, (hipStream_t)stream, &w);
+}
+
+// ---------------------------------------------------------------- one window of the temporal stage
+namespace {
+struct WindowWs {
+    size_t step = 0, xn = 0, px = 0;             // the cell update's own workspace, normalised frames, x-half sums
+    size_t total() const { return step + xn + px; }
+};
+
+bool window_batches_x(const CClstm& Cl, int n_clips) {
+    static const int env = []() { const char* e = getenv("CP360_XBATCH"); return e ? atoi(e) : -1; }();
+    if (!Cl.split_ok) return false;
+    return env < 0 ? n_clips <= 2 : env != 0;
+}
+
+int window_plan(cp360_ctx* ctx, int n_clips, int T, int face, WindowWs* w) {
+    CClstm& Cl = ctx->cl;
+    if (!Cl.loaded) return CP360_ERR_NULL;
+    if (n_clips <= 0 || T <= 0 || face <= 0 || Cl.cin != Cl.ch) return CP360_ERR_BAD_SHAPE;
+    ClstmWs s;
+    int rc = clstm_run(ctx, true, nullptr, nullptr, nullptr, nullptr, n_clips, face, nullptr, nullptr, 0, nullptr, 0, nullptr, &s);
+    if (rc) return rc;
+    w->step = s.total();
+    if (window_batches_x(Cl, n_clips)) {
+        const size_t M = (size_t)6 * n_clips * face * face;
+        // the h half's split-K slabs can need more room than the full convolution's (another split count)
+        Run run;
+        run.dry = true;
+        run.dtype = Cl.dtype;
+        run.finish_extra = (const float*)16;                   // (dry: only "the finish has an extra addend", never read)
+        if ((rc = run.conv(Cl.c1h, nullptr, 6 * n_clips, face, face, nullptr, 0, nullptr, 4 * Cl.ch, 0, nullptr, 0, 0, 0, false, false,
+                           nullptr, 0, nullptr)))
+            return rc;
+        if (align_up(run.partial_need) > s.partial) w->step += align_up(run.partial_need) - s.partial;
+        w->xn = align_up((size_t)T * M * Cl.cin * es_of(Cl.dtype));
+        w->px = align_up((size_t)T * M * 4 * Cl.ch * sizeof(float));
+    }
+    return CP360_OK;
+}
+}  // namespace
+
+extern "C" size_t cp360_clstm_window_workspace_bytes(cp360_ctx* ctx, int n_clips, int T, int face) {
+    if (!ctx) return 0;
+    WindowWs w;
+    return window_plan(ctx, n_clips, T, face, &w) ? 0 : w.total();
+}
+
+extern "C" int cp360_clstm_window(cp360_ctx* ctx, const float* cam, size_t clip_stride, int n_clips, int T, int face, void* xh,
+                                  float* cell0, float* cell1, float* h_out, float* h_all, float* minmax, float* mm_scratch,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !cam || !xh || !cell0 || !cell1 || !h_out || !minmax || !mm_scratch || !workspace) return CP360_ERR_NULL;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CP360_ERR_HIP;
+    CClstm& Cl = ctx->cl;
+    WindowWs w;
+    int rc = window_plan(ctx, n_clips, T, face, &w);
+    if (rc) return rc;
+    if (((size_t)workspace & 255) != 0) return CP360_ERR_ALIGN;
+    if (workspace_bytes < w.total()) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 6 * face * face, C = Cl.cin, H = Cl.ch, n6 = 6 * n_clips, c4 = 4 * H, es = es_of(Cl.dtype);
+    const size_t M = (size_t)n_clips * P;
+    const size_t per_clip = (size_t)T * P * C, stride = clip_stride ? clip_stride : per_clip;
+    unsigned char* ws = (unsigned char*)workspace;
+    // test_temporal.py:66-67: min / max over the whole window;  :70-73: hidden = cell = normalised frame 0
+    if ((rc = cp360_window_minmax(cam, minmax, mm_scratch, n_clips, per_clip, stride, st))) return rc;
+    if ((rc = cp360_window_normalize(cam, minmax, xh, Cl.dtype, C + H, C, cell0, n_clips, T, 0, P, C, stride, st))) return rc;
+    const bool batch = window_batches_x(Cl, n_clips);
+    float* px = nullptr;
+    Run run;                                                  // for the batched path's convolutions
+    run.st = st;
+    run.dtype = Cl.dtype;
+    if (batch) {
+        unsigned char* xn = ws + w.step;
+        px = (float*)(ws + w.step + w.xn);
+        if ((rc = cp360_window_normalize_frames(cam, minmax, xn, Cl.dtype, n_clips, T, P, C, stride, st))) return rc;
+        // x half of Conv1 for all T frames: M = T * 6 face^2 * n_clips, K = 9 Cin, no split-K, raw f32 sums in slab order
+        if ((rc = run.conv(Cl.c1x, xn, T * n6, face, face, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, 0, true, c4 % 32 == 0, px, 1, nullptr)))
+            return rc;
+    } else if ((rc = cp360_window_normalize(cam, minmax, xh, Cl.dtype, C + H, 0, nullptr, n_clips, T, 0, P, C, stride, st))) {
+        return rc;                                            // frame 0 is fed again first (:76-79)
+    }
+    float* c[2] = {cell0, cell1};
+    for (int t = 0; t < T; ++t) {
+        float* hf = h_all ? h_all + (size_t)t * M * H : (t == T - 1 ? h_out : nullptr);
+        if (!batch) {
+            const float* xnext = t + 1 < T ? cam + (size_t)(t + 1) * P * C : nullptr;   // frame t+1's normalisation rides on the gates
+            if ((rc = cp360_clstm_step(ctx, xh, c[t & 1], c[(t + 1) & 1], hf, n_clips, face, xnext, minmax, stride, ws, w.step, st)))
+                return rc;
+            continue;
+        }
+        // Conv1 = finish(h half's split-K slabs + the x half's sums of frame t + bias) -> relu;  Conv2;  Gates;  gate epilogue
+        unsigned char* a1 = ws;
+        const size_t act = align_up(M * c4 * es);
+        unsigned char* a2 = ws + act;
+        run.partial = (float*)(ws + 2 * act);
+        run.partial_cap = w.step - 2 * act;
+        run.finish_extra = px + (size_t)t * M * c4;
+        if ((rc = run.conv(Cl.c1h, (const unsigned char*)xh + (size_t)C * es, n6, face, face, nullptr, 0, a1, c4, 0, nullptr, 0, 0, 0, false,
+                           false, nullptr, 0, nullptr)))
+            return rc;
+        if ((rc = run.conv(Cl.c2, a1, n6, face, face, nullptr, 0, a2, c4, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr))) return rc;
+        int splits = 1;
+        const bool sr = c4 % 32 == 0;
+        if ((rc = run.conv(Cl.g, a2, n6, face, face, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, 0, true, sr, nullptr, 0, &splits))) return rc;
+        if ((rc = cp360_lstm_gates_next(run.partial, splits, Cl.gbias, c[t & 1], c[(t + 1) & 1], xh, Cl.dtype, C + H, C, hf, (int)M, H,
+                                        sr ? 1 : 0, nullptr, nullptr, 0, P, 0, st)))
+            return rc;
+    }
+    if (h_all && hipMemcpyAsync(h_out, h_all + (size_t)(T - 1) * M * H, M * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return CP360_ERR_HIP;
+    return CP360_OK;
 }

@@ -288,8 +288,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void window_normalize_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ minmax, T* __restrict__ y,
                                                                int ld_y, int y_coff, float* __restrict__ y2,
-                                                               size_t clip_stride, int t, int P, int C) {
+                                                               size_t clip_stride, int t, int P, int C,
+                                                               size_t y_tstride) {
     const int b = blockIdx.y;
+    t += blockIdx.z;                                           // cp360_window_normalize_frames: one grid layer per frame
+    y += (size_t)blockIdx.z * y_tstride;
     const float mn = minmax[b * 2], mx = minmax[b * 2 + 1];
     const float den = mx - mn;
     const int cq = C / 4;
@@ -319,13 +322,42 @@ extern "C" int cp360_window_normalize(const float* x, const float* minmax, void*
     if (blocks > 1024) blocks = 1024;
     if (y_dtype == CP360_F32)
         hipLaunchKernelGGL((window_normalize_kernel<float>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
-                           (float*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
+                           (float*)y, ld_y, y_coff, y2, clip_stride, t, P, C, (size_t)0);
     else if (y_dtype == CP360_BF16)
         hipLaunchKernelGGL((window_normalize_kernel<bf16_raw>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
-                           (bf16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
+                           (bf16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C, (size_t)0);
     else if (y_dtype == CP360_F16)
         hipLaunchKernelGGL((window_normalize_kernel<f16_raw>), dim3((unsigned)blocks, B), dim3(256), 0, st, x, minmax,
-                           (f16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C);
+                           (f16_raw*)y, ld_y, y_coff, y2, clip_stride, t, P, C, (size_t)0);
+    else
+        return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+// All T frames of every window at once: y [T, B, P, C] (dense, dtype y_dtype) - the input of the batched x half of the
+// ConvLSTM's first convolution (csrc/ctx.hip: cp360_clstm_window).
+extern "C" int cp360_window_normalize_frames(const float* x, const float* minmax, void* y, int y_dtype, int B, int T, int P,
+                                             int C, size_t clip_stride, void* stream) {
+    if (!x || !minmax || !y) return CP360_ERR_NULL;
+    if (B <= 0 || T <= 0 || P <= 0 || C <= 0 || B > 65535 || T > 65535) return CP360_ERR_BAD_SHAPE;
+    if (clip_stride == 0) clip_stride = (size_t)T * P * C;
+    if (C % 4 != 0 || clip_stride % 4 != 0) return CP360_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)P * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    const dim3 grid((unsigned)blocks, B, T);
+    const size_t ts = (size_t)B * P * C;
+    if (y_dtype == CP360_F32)
+        hipLaunchKernelGGL((window_normalize_kernel<float>), grid, dim3(256), 0, st, x, minmax, (float*)y, C, 0, nullptr,
+                           clip_stride, 0, P, C, ts);
+    else if (y_dtype == CP360_BF16)
+        hipLaunchKernelGGL((window_normalize_kernel<bf16_raw>), grid, dim3(256), 0, st, x, minmax, (bf16_raw*)y, C, 0, nullptr,
+                           clip_stride, 0, P, C, ts);
+    else if (y_dtype == CP360_F16)
+        hipLaunchKernelGGL((window_normalize_kernel<f16_raw>), grid, dim3(256), 0, st, x, minmax, (f16_raw*)y, C, 0, nullptr,
+                           clip_stride, 0, P, C, ts);
     else
         return CP360_ERR_BAD_DTYPE;
     CP360_CHECK_HIP();

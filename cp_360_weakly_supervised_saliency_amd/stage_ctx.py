@@ -170,3 +170,29 @@ class ClstmStage:
             mm, stride = ptr(minmax), int(clip_stride)
         check(lib().cp360_clstm_step(self.ctx.h, ptr(xh), ptr(c_prev), ptr(c_next), ptr(h_f32), B, w, xp, mm, stride, ptr(ws),
                                      ws.numel(), stream()))
+
+    def window(self, cam, B, T, w, xh, cells, h_out, minmax, scratch, clip_stride=0, h_all=None):
+        """cp360_clstm_window: min / max, hidden = cell = frame 0, T cell updates for B windows in lock step (one C call).
+        cam f32 (window b at + b * clip_stride elements; 0 = dense [B, T, P, C]); h_out f32 [6B, w, w, H] = the final hidden
+        state; h_all (optional) f32 [T, 6B, w, w, H] = the hidden state after every step."""
+        self._load(w)
+        c = self.cell
+        dt = precision_dtype(c.precision)
+        require_gpu(cam, xh, cells[0], cells[1], h_out, minmax, scratch, h_all)
+        P, Cc, Hh = 6 * w * w, c.input_size, c.hidden_size
+        stride = int(clip_stride) or T * P * Cc
+        if cam.dtype != torch.float32 or not cam.is_contiguous() or cam.numel() < (B - 1) * stride + T * P * Cc:
+            raise ValueError("cam must be a contiguous f32 tensor holding T frames of [6 w^2, Cin] per window")
+        if xh.dtype != dt or not xh.is_contiguous() or tuple(xh.shape) != (6 * B, w, w, Cc + Hh):
+            raise ValueError("xh must be a contiguous %s [6B, w, w, Cin + H] tensor" % dt)
+        for name, t, n in (('cell0', cells[0], 6 * B * w * w * Hh), ('cell1', cells[1], 6 * B * w * w * Hh),
+                           ('h_out', h_out, 6 * B * w * w * Hh), ('minmax', minmax, 2 * B), ('scratch', scratch, 512 * B),
+                           ('h_all', h_all, T * 6 * B * w * w * Hh)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < n):
+                raise ValueError("%s must be a contiguous f32 tensor of at least %d elements" % (name, n))
+        nbytes = lib().cp360_clstm_window_workspace_bytes(self.ctx.h, B, T, w)
+        if nbytes == 0:
+            raise ValueError("unsupported window geometry (needs input_size == hidden_size)")
+        ws = self.ctx.workspace(('window', B, T, w), nbytes)
+        check(lib().cp360_clstm_window(self.ctx.h, ptr(cam), int(clip_stride), B, T, w, ptr(xh), ptr(cells[0]), ptr(cells[1]),
+                                       ptr(h_out), ptr(h_all), ptr(minmax), ptr(scratch), ptr(ws), ws.numel(), stream()))

@@ -46,6 +46,22 @@ class ClipRunner:
         if sliding and cam.shape[0] != B + T - 1:
             raise ValueError("a sliding run over %d windows of %d frames needs %d frames" % (B, T, B + T - 1))
         stride = P * cin if sliding else 0
+        from .. import stage_ctx
+        if stage_ctx.USE_CTX:
+            # the whole window in ONE C call (cp360_clstm_window, csrc/ctx.hip): min / max, initial state, T cell updates -
+            # and, with at most two windows per call, Conv1's x half batched over all T frames
+            stage = self.cell.__dict__.get('_stage')
+            if stage is None:
+                stage = self.cell.__dict__['_stage'] = stage_ctx.ClstmStage(self.cell)
+            h_all = None
+            if return_all_steps:
+                h_all = torch.empty((T,) + tuple(self.h_f32.shape), dtype=torch.float32, device=self.h_f32.device)
+            stage.window(cam, B, T, self.w, self.xh, self.c, self.h_f32, self.minmax, self.scratch, clip_stride=stride, h_all=h_all)
+            if return_all_steps:
+                sal = torch.stack([self.c2e.saliency(h_all[t], layout='nhwc') for t in range(T)], dim=1)
+            else:
+                sal = self.c2e.saliency(self.h_f32, layout='nhwc')
+            return (sal, self.h_f32) if return_hidden else sal
         ops.window_minmax(cam, B, T * P * cin, self.minmax, self.scratch, stride)
         # hidden = cell = (frame0 - mn) / (mx - mn)
         ops.window_normalize(cam, self.minmax, self.xh, cin, self.c[0], B, T, 0, P, cin, stride)

@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 302
+#define CP360_VERSION 303
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -233,6 +233,10 @@ int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, const void* in
 /* out = act(sum_s partial[s] + bias (+ residual)) in d->dtype at the desc's ld_out/out_coff. */
 int cp360_conv_finish(const cp360_conv_desc* d, const float* partial, const float* bias,
                       const void* residual, void* out, void* stream);
+/* The same with one more f32 addend `extra` [M, c_out] in the slabs' column order (d->slab_rows), e.g. the batched
+ * x half of the ConvLSTM's first convolution (cp360_clstm_window). */
+int cp360_conv_finish_add(const cp360_conv_desc* d, const float* partial, const float* extra, const float* bias,
+                          const void* residual, void* out, void* stream);
 
 /* ------------------------------------------------------------------ K3a: resident-patch stem
  * conv 7x7 stride 2 (3 -> 64) + folded BatchNorm + ReLU of model/resnet_cubic.py:115-128,163-168 on the
@@ -404,6 +408,10 @@ int cp360_window_normalize(const float* x, const float* minmax, void* y, int y_d
                            int ld_y, int y_coff, float* y2, int B, int T, int t,
                            int P, int C, size_t clip_stride, void* stream);
 
+/* All T frames of every window in one launch: y [T, B, P, C] (dense, y_dtype) = (x[b, t] - mn_b) / (mx_b - mn_b). */
+int cp360_window_normalize_frames(const float* x, const float* minmax, void* y, int y_dtype, int B, int T, int P, int C,
+                                  size_t clip_stride, void* stream);
+
 /* ------------------------------------------------------------------ K9: overlay renderer
  * utils/utils.py:9-25 as used by temporal_model/test_temporal.py:90-97.
  * cp360_overlay_colorize: heat f32 [h, w] (optionally squared first, test_temporal.py:94) -> min-max
@@ -501,6 +509,24 @@ size_t cp360_clstm_workspace_bytes(cp360_ctx* ctx, int n_clips, int face);
 int cp360_clstm_step(cp360_ctx* ctx, void* xh, const float* c_prev, float* c_next, float* h_f32, int n_clips, int face,
                      const float* x_next, const float* minmax, size_t clip_stride, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* One WINDOW of the temporal stage in one call (temporal_model/test_temporal.py:63-80 for n_clips windows in lock step):
+ * min / max over each window, hidden = cell = normalised frame 0, T cell updates (frame 0 fed again first).
+ *   cam       f32: window b = T frames of [6 face^2, Cin] (pixel-major) starting at cam + b * clip_stride elements
+ *             (clip_stride 0 = dense T * P * Cin; P * Cin = the reference's stride-1 sliding window over one sequence)
+ *   xh        [6 n_clips, face, face, Cin + H] scratch in the loaded dtype (the fused [x | h] buffer of cp360_clstm_step)
+ *   cell0/1   f32 [6 n_clips, face, face, H] scratch (ping-pong cell state)
+ *   h_out     f32 [6 n_clips, face, face, H]: the final hidden state (:80);  h_all (optional) f32 [T, 6 n_clips, face, face, H]:
+ *             the hidden state after EVERY step (return_all_steps)
+ *   minmax    f32 [n_clips, 2] (out), mm_scratch f32 [n_clips * 512]
+ * Needs Cin == H (:70-73).  Planning inside: with at most two windows per call the ConvLSTM convolutions are weight-stream
+ * bound, and the x half of Conv1 (K = 9 Cin, no recurrence) runs ONCE for all T frames (one M = T * 6 face^2 * n_clips GEMM without
+ * split-K; its f32 result joins the h half's split-K slabs in cp360_conv_finish_add): Conv1's x weights stream once per window
+ * instead of T times.  CP360_XBATCH=0 / 1 forces it off / on.  workspace: cp360_clstm_window_workspace_bytes. */
+size_t cp360_clstm_window_workspace_bytes(cp360_ctx* ctx, int n_clips, int T, int face);
+int cp360_clstm_window(cp360_ctx* ctx, const float* cam, size_t clip_stride, int n_clips, int T, int face, void* xh,
+                       float* cell0, float* cell1, float* h_out, float* h_all, float* minmax, float* mm_scratch,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
