@@ -181,10 +181,97 @@ __global__ __launch_bounds__(256) void cubepad_nchw_strip_kernel(const unsigned 
     }
 }
 
+
+// ---------------------------------------------------------------- NCHW, small faces: whole cubes through LDS (round 3)
+// Faces whose rows are shorter than a cache line (28x28 / 14x14 / 7x7: layers 2-4 and the ConvLSTM) are where the
+// element-per-lane kernel sits at 0.09-0.16 of the HBM peak (profiles/r02f_hbm_kernels.md): 2-4 byte accesses and one
+// cubepad_src() evaluation per element.  Here a workgroup item is (cube g, channel range [c0, c0 + CH)):
+//   * its input is 6 CONTIGUOUS byte ranges (face f, channels c0 .. c0+CH-1: CH * n^2 elements), read with 16-byte loads
+//     into LDS - coalesced HBM reads of whole lines although a plane is only 98-1568 bytes;
+//   * CubePad copies only between the 6 faces of one cube (cube_pad.py:114-216), so every output element of the item's
+//     6 x CH padded planes is one of those LDS elements: a table [6][Hp][Wp] of (source face, offset) built ONCE per
+//     workgroup from cubepad_src() (the face-border strips and the replicated corners of make_cubepad_edge are just table
+//     entries) drives the gather;
+//   * its output is 6 contiguous byte ranges too (CH * Hp * Wp elements per face), assembled 16 bytes per lane and written
+//     with aligned 16-byte stores.
+// Workgroups are persistent over items, so the table costs 6 Hp Wp / 256 evaluations per thread once.  Needs n <= 32,
+// 16-byte aligned ranges (checked by the launcher: c0 * n^2 * ES and c0 * Hp * Wp * ES multiples of 16); anything else
+// takes the kernels above.  Bit-exact like every CubePad kernel (pure copy).
+template <int ES>
+__global__ __launch_bounds__(256) void cubepad_nchw_cube_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ y,
+                                                                int C, CubePadGeom g, int CH, int n_items, int ranges) {
+    typedef typename ElemOf<ES>::T T;
+    constexpr int E = 16 / ES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char cube_lds[];
+    const int n = g.n, nn = n * n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr, HW = Hp * Wp;
+    unsigned short* tab = reinterpret_cast<unsigned short*>(cube_lds);                    // [6][HW]: sf << 10 | off  (n^2 <= 1024)
+    const int tab_bytes = (6 * HW * 2 + 15) & ~15;
+    T* in_s = reinterpret_cast<T*>(cube_lds + tab_bytes);                                // [6][CH * nn]
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 6 * HW; idx += 256) {
+        const int f = idx / HW, q = idx - f * HW;
+        const int i = q / Wp, j = q - i * Wp;
+        const int s = cubepad_src(f, i, j, g);
+        const int sf = s / nn;
+        tab[idx] = (unsigned short)((sf << 10) | (s - sf * nn));
+    }
+    const int in_chunks = CH * nn * ES / 16, out_chunks = CH * HW * ES / 16;              // per face (launcher: exact)
+    const size_t in_face = (size_t)C * nn * ES, out_face = (size_t)C * HW * ES;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int grp = item / ranges, c0 = (item - grp * ranges) * CH;
+        __syncthreads();                                     // table built / previous item's gather done with in_s
+        const unsigned char* xin = x + (size_t)grp * 6 * in_face + (size_t)c0 * nn * ES;
+        for (int k = tid; k < 6 * in_chunks; k += 256) {
+            const int f = k / in_chunks, ck = k - f * in_chunks;
+            const cp_u32x4 v = *reinterpret_cast<const cp_u32x4*>(xin + (size_t)f * in_face + (size_t)ck * 16);
+            *reinterpret_cast<cp_u32x4*>(reinterpret_cast<unsigned char*>(in_s) + ((size_t)f * in_chunks + ck) * 16) = v;
+        }
+        __syncthreads();
+        unsigned char* yout = y + (size_t)grp * 6 * out_face + (size_t)c0 * HW * ES;
+        for (int k = tid; k < 6 * out_chunks; k += 256) {
+            const int f = k / out_chunks, ck = k - f * out_chunks;
+            int e0 = ck * E;                                 // first element of the chunk inside the face's CH planes
+            int ch = e0 / HW, q = e0 - ch * HW;
+            const unsigned short* tf = tab + f * HW;
+            T tmp[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const unsigned t = tf[q];
+                tmp[e] = in_s[(t >> 10) * (CH * nn) + ch * nn + (t & 1023u)];
+                if (++q == HW) { q = 0; ++ch; }
+            }
+            cp_u32x4 v;
+            __builtin_memcpy(&v, tmp, 16);
+            *reinterpret_cast<cp_u32x4*>(yout + (size_t)f * out_face + (size_t)ck * 16) = v;
+        }
+    }
+}
+
 template <typename T>
 static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom& g, hipStream_t st) {
     const int Wp = g.n + g.pl + g.pr;
     const int planes = (n6 / 6) * C;
+    {   // small faces: whole cubes through LDS.  CH channels per item: the largest divisor-free choice whose input fits
+        // ~24 KiB and whose per-face input / output ranges are whole 16-byte chunks at 16-byte aligned addresses
+        constexpr int ES = (int)sizeof(T);
+        const int nn = g.n * g.n, HW = (g.n + g.pt + g.pd) * Wp;
+        static const int no_cube = []() { const char* e = getenv("CP360_CUBEPAD_NOCUBE"); return e ? atoi(e) : 0; }();   // A/B switch
+        if (!no_cube && g.n <= 32 && HW <= 1444 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
+            int CH = 0;
+            for (int ch = 1; ch <= C && (size_t)6 * ch * nn * ES <= 24 * 1024; ++ch)
+                if (C % ch == 0 && (ch * nn * ES) % 16 == 0 && (ch * HW * ES) % 16 == 0) CH = ch;
+            if (CH > 0 && ((size_t)C * nn * ES) % 16 == 0 && ((size_t)C * HW * ES) % 16 == 0) {
+                const int ranges = C / CH;
+                const long long items = (long long)(n6 / 6) * ranges;
+                const size_t lds = (size_t)((6 * HW * 2 + 15) & ~15) + (size_t)6 * CH * nn * ES;
+                long long blocks = items < 256 * 4 ? items : 256 * 4;
+                hipLaunchKernelGGL((cubepad_nchw_cube_kernel<ES>), dim3((unsigned)blocks), dim3(256), lds, st,
+                                   (const unsigned char*)x, (unsigned char*)y, C, g, CH, (int)items, ranges);
+                CP360_CHECK_HIP();
+                return CP360_OK;
+            }
+        }
+    }
     {   // strip kernel: pads of at most 4 (every pad of the network is 1 or 3), strips within the 64 KiB LDS default
         const int P = max(max(g.pl, g.pr), max(g.pt, g.pd));
         constexpr int ES = (int)sizeof(T);
@@ -194,9 +281,10 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
             const char* e = getenv("CP360_CUBEPAD_ELEMENTWISE");      // A/B switch (tools/hbm_kernels.py)
             return e ? atoi(e) : 0;
         }();
-        // (rows of at least 128 bytes: on the small faces of layer3/4 and the ConvLSTM almost every chunk touches
-        //  padding and the element-per-lane kernel below is faster - measured, profiles/r02_hbm_kernels.md)
-        if (!no_strip && P >= 1 && P <= g.n && g.n * ES >= 128 && lds <= 64 * 1024 && (long long)Hp * Wp < (1 << 22) &&
+        // (rows of at least 112 bytes - 56x56 f16 faces: 245 -> 149 us against the element-per-lane kernel, round 3; smaller
+        //  faces take the whole-cube kernel above)
+        static const int strip_min = []() { const char* e = getenv("CP360_CUBEPAD_STRIP_MIN"); return e ? atoi(e) : 112; }();   // A/B switch
+        if (!no_strip && P >= 1 && P <= g.n && g.n * ES >= strip_min && lds <= 64 * 1024 && (long long)Hp * Wp < (1 << 22) &&
             (reinterpret_cast<size_t>(y) % ES) == 0) {
             const long long items = (long long)planes * 6;
             long long blocks = (items + 3) / 4;

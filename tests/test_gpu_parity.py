@@ -68,6 +68,29 @@ def test_cubepad_every_element_size(dtype):
     assert got.dtype == dtype and np.array_equal(got.view(bits).numpy(), want)
 
 
+@pytest.mark.parametrize('shape,pad,dtype', [
+    ((12, 16, 7, 7), 1, torch.float32),          # ConvLSTM faces (clstm.py:38: CubePad(1) on [6B, C, 7, 7])
+    ((24, 2000, 7, 7), 1, torch.float32),        # ... at the cell's real width
+    ((6, 256, 14, 14), 1, torch.bfloat16),       # layer3 (resnet_cubic.py:85-106)
+    ((12, 128, 28, 28), 1, torch.float16),       # layer2
+    ((6, 8, 8, 8), [1, 2, 3, 1], torch.float32), # asymmetric pads (cube_pad.py:60-70): corners from the deeper strip
+    ((6, 32, 7, 7), 3, torch.uint8),
+    ((6, 4, 32, 32), 3, torch.float64),
+    ((6, 6, 9, 9), 2, torch.float32),            # plane bytes not a multiple of 16 for most channel counts: fallback or CH = 4
+])
+def test_cubepad_nchw_small_faces_whole_cube_kernel(shape, pad, dtype):
+    """csrc/cubepad.hip, cubepad_nchw_cube_kernel: (cube, channel range) items staged through LDS, the CubePad map as a
+    per-workgroup table - bit-exact against the oracle (model/cube_pad.py:95-216) for the network's small faces, asymmetric
+    pads, every element size; and identical to the element-per-lane kernel (CP360 A/B path: channels_last input takes
+    the NHWC kernel, so the comparison partner is the oracle)."""
+    x = hashrng.integers(81, shape, 0, 250).astype(np.float64)
+    xt = torch.from_numpy(x).to(dtype)
+    bits = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[xt.element_size()]
+    want = o_cubepad.cubepad(xt.view(bits).numpy(), pad)
+    got = CubePad(pad)(xt.to(DEV)).cpu()
+    assert got.dtype == dtype and np.array_equal(got.view(bits).numpy(), want)
+
+
 def test_cubepad_nhwc_and_channel_padding():
     x = hashrng.integers(78, (6, 7, 14, 14), 0, 1 << 20).astype(np.float32)       # NCHW
     want = o_cubepad.cubepad(x, 1)
