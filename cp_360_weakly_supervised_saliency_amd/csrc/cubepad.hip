@@ -3,6 +3,7 @@
 // Semantics: model/cube_pad.py:28-42,95-216 (see common.h: cubepad_src).
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 // ---------------------------------------------------------------- NCHW
 // One workgroup per (group g, channel c): it writes the 6 padded planes of that
@@ -182,6 +183,573 @@ __global__ __launch_bounds__(256) void cubepad_nchw_strip_kernel(const unsigned 
 }
 
 
+// ---------------------------------------------------------------- NCHW, large faces: run copies + pad stream (round 3)
+// The strip kernel above is VALU-bound, not HBM-bound (tools/_exp timing variants, profiles/r03_cubepad_plane.md: the run
+// pass alone takes 393 us on [384,64,112,112] f16 where a plain copy of the same bytes takes 250 us - ~40 instructions
+// per 16-byte chunk, because the per-item values live in vector registers and every chunk pays two float-reciprocal
+// divisions; the pad pass costs as much again in branchy per-element code).  Same decomposition, cheaper arithmetic:
+//   * the wave index is made uniform (readfirstlane), so item / plane / face / base pointers are scalar;
+//   * pass 1 (runs = chunks fully inside a centre row) steps (row, chunk-in-row) incrementally - no division;
+//   * every pad element of the padded plane, in OUTPUT order, is staged in LDS once per item ("pad stream" PS: the padded
+//     plane with its centre elements removed: pt full rows, then [pl left | pr right] per centre row, then pd full rows;
+//     so the PS index of a pad element q is q - #centre elements before q).  Strip lines are affine in the neighbour
+//     face (cubepad_src: row / col are each one of k, n-p+k, a, n-1-a): a 16-entry (base, step) table per item replaces
+//     cubepad_src() per element; only the <= (pt+pd)(pl+pr) corner elements evaluate it;
+//   * every chunk that is not a run - pad rows, the 1-3 chunks between consecutive runs, the head / tail chunks a plane
+//     shares with its neighbours - is one branch-free routine: E consecutive output elements are [centre stream A]
+//     [pads][centre stream B] (n >= 2E + pl + pr: at most one centre -> pad -> centre transition), so two possibly
+//     misaligned 16-byte loads A, B positioned so that element e of the chunk is A[e] / B[e], E LDS reads PS[base + e]
+//     at immediate offsets, and two compares + selects per element.
+// Bit-exact like every CubePad kernel (pure copy).
+template <int ES>
+__global__ __launch_bounds__(256) void cubepad_nchw_plane_kernel(const unsigned char* __restrict__ x,
+                                                                 unsigned char* __restrict__ y, int C, CubePadGeom g,
+                                                                 int n_items, long long total_in, float rcp_wp, float rcp_n,
+                                                                 float rcp_cpr, int dq, int dm, int maxc, float rcp_maxc,
+                                                                 int ps_alloc, int rbw) {
+    typedef typename ElemOf<ES>::T T;
+    constexpr int E = 16 / ES;                               // elements per 16-byte chunk
+    constexpr int LOG_E = E == 16 ? 4 : (E == 8 ? 3 : (E == 4 ? 2 : 1));
+    constexpr int UNR = 4;                                   // run chunks in flight per lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char strip_raw[];
+    const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr, LR = g.pl + g.pr;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nlines = g.pt + g.pd + LR, nstrip = nlines * n;
+    const int nn = n * n, plane_elems = Hp * Wp;
+    const int ps_mid = g.pt * Wp;                            // PS index of centre row 0's first pad
+    const int ps_bot = ps_mid + n * LR;                      // PS index of the first bottom-row element
+    int* ltab = reinterpret_cast<int*>(strip_raw) + wave * 32;                  // [16 lines][base, step]
+    T* ps = reinterpret_cast<T*>(strip_raw + 512) + (size_t)wave * ps_alloc + E;   // E elements of slack either side
+    const int in_face = C * nn;                              // (6 * in_face < 2^31: launcher)
+    const size_t out_face = (size_t)C * plane_elems;
+    const int cpr = (n >> LOG_E) + 1;                        // chunks per run, upper bound
+    auto div_by = [](int q, int d, float rcp) -> int {       // exact for 0 <= q < 2^24
+        int r = (int)((float)q * rcp);
+        r -= (r * d > q);
+        r += ((r + 1) * d <= q);
+        return r;
+    };
+    for (int item = blockIdx.x * 4 + wave; item < n_items; item += gridDim.x * 4) {
+        const int plane = item / 6, f = item - plane * 6;
+        const int grp = plane / C, c = plane - grp * C;
+        const long long cube_off = (long long)grp * 6 * in_face + (long long)c * nn;   // elements from x
+        const long long xf_off = cube_off + (long long)f * in_face;
+        const T* xin = reinterpret_cast<const T*>(x) + cube_off;
+        const T* xf = reinterpret_cast<const T*>(x) + xf_off;
+        // ---- the strip lines of this face as (element offset from xin, step) pairs
+        if (lane < nlines) {
+            const int k = lane;
+            int i0, j0, di = 0, dj = 0;
+            if (k < g.pt)                      { i0 = k;                        j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd)          { i0 = n + k;                    j0 = g.pl; dj = 1; }      // pt + n + (k - pt)
+            else if (k < g.pt + g.pd + g.pl)   { i0 = g.pt;                     j0 = k - g.pt - g.pd; di = 1; }
+            else                               { i0 = g.pt;                     j0 = n + k - g.pt - g.pd; di = 1; }   // pl + n + (k - pt - pd - pl)
+            const int s0 = cubepad_src(f, i0, j0, g), s1 = cubepad_src(f, i0 + di, j0 + dj, g);
+            const int sf = s0 / nn;
+            ltab[2 * k] = sf * in_face + (s0 - sf * nn);
+            ltab[2 * k + 1] = s1 - s0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- pad stream: strips ...
+        for (int idx = lane; idx < nstrip; idx += 64) {
+            const int k = div_by(idx, n, rcp_n), a = idx - k * n;
+            const int base = ltab[2 * k], step = ltab[2 * k + 1];
+            int pos;
+            if (k < g.pt)                      pos = k * Wp + g.pl + a;
+            else if (k < g.pt + g.pd)          pos = ps_bot + (k - g.pt) * Wp + g.pl + a;
+            else if (k < g.pt + g.pd + g.pl)   pos = ps_mid + a * LR + (k - g.pt - g.pd);
+            else                               pos = ps_mid + a * LR + (k - g.pt - g.pd);       // pl + (k - pt - pd - pl)
+            ps[pos] = xin[base + a * step];
+        }
+        // ---- ... and corners (make_cubepad_edge: cube_pad.py:44-93)
+        const int ncorner = (g.pt + g.pd) * LR;
+        for (int idx = lane; idx < ncorner; idx += 64) {
+            const int ci = idx / LR, cj = idx - ci * LR;
+            const int i = ci < g.pt ? ci : n + ci, j = cj < g.pl ? cj : n + cj;
+            const int s = cubepad_src(f, i, j, g);
+            const int sf = s / nn;
+            const int pos = ci < g.pt ? i * Wp + j : ps_bot + (ci - g.pt) * Wp + j;
+            ps[pos] = xin[sf * in_face + (s - sf * nn)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned char* yb = y + ((size_t)grp * 6 * out_face + (size_t)f * out_face + (size_t)c * plane_elems) * ES;
+        const size_t a0 = reinterpret_cast<size_t>(yb), a1 = a0 + (size_t)plane_elems * ES;
+        const size_t c0 = a0 & ~(size_t)15;
+        unsigned char* c0p = reinterpret_cast<unsigned char*>(c0);
+        const int head = (int)(a0 - c0) / ES;                // elements of chunk 0 that belong to the previous plane
+        const int nchunks = (int)((a1 - c0 + 15) >> 4);
+        const int rowA = g.pt * Wp + g.pl + head;
+        auto run_begin = [&](int r) -> int { return (r * Wp + rowA + E - 1) >> LOG_E; };   // first chunk fully inside centre row r
+        auto run_end = [&](int r) -> int { return (r * Wp + rowA + n) >> LOG_E; };
+        auto load_vec = [&](long long goff) -> cp_u32x4 {     // 16 bytes at element goff of x; the tensor's first / last chunk may hang over its ends
+            cp_u32x4 v;
+            if (goff >= 0 && goff + E <= total_in) {
+                __builtin_memcpy(&v, reinterpret_cast<const T*>(x) + goff, 16);
+            } else {
+                T tmp[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const long long t = goff + e;
+                    tmp[e] = (t >= 0 && t < total_in) ? reinterpret_cast<const T*>(x)[t] : (T)0;
+                }
+                __builtin_memcpy(&v, tmp, 16);
+            }
+            return v;
+        };
+        auto slow_chunk = [&](int ch) __attribute__((always_inline)) {
+            const int q0 = ch * E - head;
+            int iA, jA;
+            if (q0 < 0) { iA = -1; jA = q0 + Wp; }
+            else        { iA = div_by(q0, Wp, rcp_wp); jA = q0 - iA * Wp; }
+            const int a = iA - g.pt;                                           // centre row of row iA when 0 <= a < n
+            const bool rowc = a >= 0 && a < n;
+            const bool q0c = rowc && jA >= g.pl && jA < g.pl + n;              // q0 is a centre element
+            const int cpos = a < 0 ? 0 : (a >= n ? nn : a * n + min(max(jA - g.pl, 0), n));   // centre elements before q0
+            const int eA = q0c ? min(E, g.pl + n - jA) : 0;                    // leading elements from centre stream A
+            const int aB = q0c ? a + 1 : (a < 0 ? 0 : (rowc ? (jA < g.pl ? a : a + 1) : n));   // centre row that starts next
+            const int eB = aB < n ? min(max((g.pt + aB) * Wp + g.pl - q0, 0), E) : E;   // elements from e = eB on are its centre
+            const cp_u32x4 va = load_vec(xf_off + (eA > 0 ? cpos : 0));
+            const cp_u32x4 vb = load_vec(xf_off + (eB < E ? aB * n - eB : 0));
+            T ta[E], tb[E], tv[E];
+            __builtin_memcpy(ta, &va, 16);
+            __builtin_memcpy(tb, &vb, 16);
+            const T* pp = ps + (q0 - cpos - eA);                               // PS index of pad element e = (q0 - cpos) + (e - eA)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const T pv = pp[e];
+                tv[e] = e < eA ? ta[e] : (e >= eB ? tb[e] : pv);
+            }
+            unsigned char* ca = c0p + ((size_t)ch << 4);
+            if (q0 >= 0 && q0 + E <= plane_elems) {
+                cp_u32x4 v;
+                __builtin_memcpy(&v, tv, 16);
+                *reinterpret_cast<cp_u32x4*>(ca) = v;
+            } else {                                                           // chunk shared with the neighbouring plane
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    if (q0 + e >= 0 && q0 + e < plane_elems) reinterpret_cast<T*>(ca)[e] = tv[e];
+            }
+        };
+        const int top_end = min(run_begin(0), nchunks);
+        const int bot_begin = max(run_end(n - 1), top_end);
+        // Row blocks: the runs of rows [r0, rend) (one UNR-deep body per wave), then at once the chunks around them - the
+        // 128-byte lines a run leaves incomplete are completed while they are still dirty in L2 (a partial line written
+        // back to HBM and completed later costs far more than its bytes: tools/_exp variants, profiles/r03_cubepad_plane.md).
+        for (int r0 = 0; r0 < n; r0 += rbw) {
+            const int rend = min(r0 + rbw, n);
+            {
+                const int rq = div_by(lane, cpr, rcp_cpr);
+                int r = r0 + rq, k = lane - rq * cpr;
+                while (r < rend) {
+                    cp_u32x4 v[UNR];
+                    unsigned doff[UNR];
+                    bool ok[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int rw = r * Wp + rowA;
+                        const int ch = ((rw + E - 1) >> LOG_E) + k;
+                        ok[u] = r < rend && ch < ((rw + n) >> LOG_E);
+                        if (ok[u]) {
+                            const unsigned soff = (unsigned)(ch * E + r * (n - Wp) - rowA);   // centre element index of the chunk's first element
+                            __builtin_memcpy(&v[u], xf + soff, 16);
+                            doff[u] = (unsigned)ch << 4;
+                        }
+                        k += dm;
+                        r += dq;
+                        if (k >= cpr) { k -= cpr; ++r; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+                        if (ok[u]) *reinterpret_cast<cp_u32x4*>(c0p + doff[u]) = v[u];
+                }
+            }
+            const int n_top = r0 == 0 ? top_end : 0, n_bot = rend == n ? nchunks - bot_begin : 0;
+            const int b0 = max(r0, 1);                                          // boundaries (rr, rr + 1) with rr + 1 in [b0, rend)
+            const int n_slow = n_top + n_bot + max(rend - b0, 0) * maxc;
+            for (int s = lane; s < n_slow; s += 64) {
+                int ch;
+                if (s < n_top) ch = s;
+                else if (s < n_top + n_bot) ch = bot_begin + (s - n_top);
+                else {
+                    const int m = s - n_top - n_bot;
+                    const int mq = div_by(m, maxc, rcp_maxc);
+                    const int rr = b0 - 1 + mq;
+                    const int lo = max(run_end(rr), top_end), hi = min(run_begin(rr + 1), bot_begin);
+                    ch = lo + (m - mq * maxc);
+                    if (ch >= hi) continue;
+                }
+                slow_chunk(ch);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                     // the next item's staging overwrites the pad stream
+    }
+}
+
+
+// ---------------------------------------------------------------- NCHW, large faces, every input byte read once (round 3)
+// The plane kernel's HBM reads are 2-3.2x the input (rocprofv3 FETCH_SIZE, profiles/r03_cubepad_plane.md): about half of
+// a cube's 24 strips are COLUMNS of the neighbouring face (cube_pad.py:114-216), so a (plane, face) item pulls a whole
+// 128-byte line per 1-4 byte pad element, and the chunks between runs re-read the first / last line of every centre row.
+// Here a workgroup item is (cube, channel) - the six planes CubePad exchanges borders between - and nothing is read twice:
+//   S1  for each face: stream the runs HBM -> registers -> HBM (as the plane kernel), and beside them capture into LDS
+//       RE[f][row][side][E]: the first and the last E elements of every centre row (one 16-byte load each, issued in the
+//       same 64-row block as the run loads of those rows, so the line is in L2), and TB[f][top|bottom][P][n]: the first /
+//       last P rows.  RE + TB hold every element a pad of ANY face of this (cube, channel) can copy (a strip lies within
+//       P <= E of a border; corners replicate strip ends) and every centre element of a non-run chunk (< E from a row end);
+//   S2  for each face: the pad stream PS (see the plane kernel) is gathered LDS -> LDS through a line table that maps the
+//       face's strip lines to affine (base, step) element offsets in RE / TB (built once per workgroup: it depends on the
+//       geometry only), then every non-run chunk is assembled from LDS alone: [row end from RE][pads from PS][row start
+//       from RE], E element reads at immediate offsets each, and written with one aligned 16-byte store.
+// HBM traffic = input + output (+ the two shared 16-byte chunks per plane).  A workgroup is 6 (or 12) waves, one (two) per
+// face: the six faces stream concurrently and independently, three workgroup barriers per item (S1 | pad streams | chunks);
+// workgroups are persistent over items.
+template <int ES>
+__global__ __launch_bounds__(768) void cubepad_nchw_channel_kernel(const unsigned char* __restrict__ x,
+                                                                   unsigned char* __restrict__ y, int C, CubePadGeom g,
+                                                                   int n_items, float rcp_wp, float rcp_n, float rcp_cpr,
+                                                                   int maxc, float rcp_maxc, int P, int ps_alloc, int rbw) {
+    typedef typename ElemOf<ES>::T T;
+    constexpr int E = 16 / ES;                               // elements per 16-byte chunk; also the width of a row-end record
+    constexpr int LOG_E = E == 16 ? 4 : (E == 8 ? 3 : (E == 4 ? 2 : 1));
+    constexpr int UNR = 8;                                   // loads in flight per lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr, LR = g.pl + g.pr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int parts = (int)(blockDim.x >> 6) / 6;            // waves per face: 1 or 2
+    const int part = wave / 6, f = wave - part * 6;          // this wave's face and its share of the rows / strips / chunks
+    const int nlines = g.pt + g.pd + LR, nstrip = nlines * n;
+    const int nn = n * n, plane_elems = Hp * Wp;
+    const int ps_mid = g.pt * Wp, ps_bot = ps_mid + n * LR;
+    const int cpr = (n >> LOG_E) + 1;
+    const int re_size = 12 * n * E, tb_face = 2 * P * n;
+    int* ltab = reinterpret_cast<int*>(smem);                                   // [6][16][base, step]
+    T* buf = reinterpret_cast<T*>(smem + 768) + E;                              // RE then TB, E elements of slack in front
+    T* ps = buf + re_size + 6 * tb_face + E + f * ps_alloc;                     // this face's pad stream (slack either side)
+    const size_t in_face = (size_t)C * nn, out_face = (size_t)C * plane_elems;
+    const int dq = 64 / cpr, dm = 64 - dq * cpr;
+    auto div_by = [](int q, int d, float rcp) -> int {       // exact for 0 <= q < 2^24
+        int r = (int)((float)q * rcp);
+        r -= (r * d > q);
+        r += ((r + 1) * d <= q);
+        return r;
+    };
+    auto lds_of = [&](int sf, int row, int col) -> int {     // RE / TB offset of element (row, col) of face sf (within E / P of a border)
+        if (row < P) return re_size + sf * tb_face + row * n + col;
+        if (row >= n - P) return re_size + sf * tb_face + (P + row - (n - P)) * n + col;
+        if (col < E) return ((sf * n + row) * 2) * E + col;
+        return ((sf * n + row) * 2 + 1) * E + col - (n - E);
+    };
+    // ---- line table (geometry only)
+    if (tid < 96) {
+        const int lf = tid >> 4, k = tid & 15;
+        if (k < nlines) {
+            int i0, j0, di = 0, dj = 0;
+            if (k < g.pt)                      { i0 = k;     j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd)          { i0 = n + k; j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd + g.pl)   { i0 = g.pt;  j0 = k - g.pt - g.pd; di = 1; }
+            else                               { i0 = g.pt;  j0 = n + k - g.pt - g.pd; di = 1; }
+            const int s0 = cubepad_src(lf, i0, j0, g), d = cubepad_src(lf, i0 + di, j0 + dj, g) - s0;
+            const int sf = s0 / nn, rem = s0 - sf * nn, row0 = rem / n, col0 = rem - row0 * n;
+            int base, step;
+            if (d == 1 || d == -1) {                         // a row of face sf: in TB
+                base = re_size + sf * tb_face + (row0 < P ? row0 : P + row0 - (n - P)) * n + col0;
+                step = d;
+            } else {                                         // a column of face sf: in RE
+                base = ((sf * n + row0) * 2 + (col0 < E ? 0 : 1)) * E + (col0 < E ? col0 : col0 - (n - E));
+                step = d > 0 ? 2 * E : -2 * E;
+            }
+            ltab[(lf * 16 + k) * 2] = base;
+            ltab[(lf * 16 + k) * 2 + 1] = step;
+        }
+    }
+    const int ra = part * n / parts, rb = (part + 1) * n / parts;               // this wave's centre rows
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int grp = item / C, c = item - grp * C;
+        const T* xf = reinterpret_cast<const T*>(x) + (size_t)grp * 6 * in_face + (size_t)c * nn + (size_t)f * in_face;
+        unsigned char* yb = y + ((size_t)grp * 6 * out_face + (size_t)c * plane_elems + (size_t)f * out_face) * ES;
+        const int head = (int)(reinterpret_cast<size_t>(yb) & 15) / ES;         // elements of chunk 0 that belong to the previous plane
+        unsigned char* c0p = yb - (size_t)head * ES;
+        const int rowA = g.pt * Wp + g.pl + head;
+        // ================= S1: runs + capture (wave = face f, rows [ra, rb))
+        {   // first / last P rows
+            const int t0 = part * tb_face / parts, t1 = (part + 1) * tb_face / parts;
+            for (int base = t0 + lane; base < t1; base += 64 * UNR) {
+                T v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int idx = base + 64 * u;
+                    if (idx < t1) v[u] = xf[idx < P * n ? idx : (n - 2 * P) * n + idx];
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (base + 64 * u < t1) buf[re_size + f * tb_face + base + 64 * u] = v[u];
+            }
+        }
+        for (int r0 = ra; r0 < rb; r0 += rbw) {
+            const int rend = min(r0 + rbw, rb);
+            for (int t = lane; t < 2 * (rend - r0); t += 64) {                  // row ends of this block
+                const int row = r0 + (t >> 1), side = t & 1;
+                cp_u32x4 v;
+                __builtin_memcpy(&v, xf + (unsigned)(row * n + (side ? n - E : 0)), 16);
+                *reinterpret_cast<cp_u32x4*>(buf + ((f * n + row) * 2 + side) * E) = v;
+            }
+            const int rq = div_by(lane, cpr, rcp_cpr);
+            int r = r0 + rq, k = lane - rq * cpr;
+            while (r < rend) {
+                cp_u32x4 v[UNR];
+                unsigned doff[UNR];
+                bool ok[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int rw = r * Wp + rowA;
+                    const int ch = ((rw + E - 1) >> LOG_E) + k;
+                    ok[u] = r < rend && ch < ((rw + n) >> LOG_E);
+                    if (ok[u]) {
+                        const unsigned soff = (unsigned)(ch * E + r * (n - Wp) - rowA);
+                        __builtin_memcpy(&v[u], xf + soff, 16);
+                        doff[u] = (unsigned)ch << 4;
+                    }
+                    k += dm;
+                    r += dq;
+                    if (k >= cpr) { k -= cpr; ++r; }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (ok[u]) *reinterpret_cast<cp_u32x4*>(c0p + doff[u]) = v[u];
+            }
+        }
+        __syncthreads();
+        // ================= S2: pads and the chunks around them, from LDS
+        {
+            const int t0 = part * nstrip / parts, t1 = (part + 1) * nstrip / parts;
+            for (int idx = t0 + lane; idx < t1; idx += 64) {
+                const int k = div_by(idx, n, rcp_n), a = idx - k * n;
+                const int base = ltab[(f * 16 + k) * 2], step = ltab[(f * 16 + k) * 2 + 1];
+                int pos;
+                if (k < g.pt)                      pos = k * Wp + g.pl + a;
+                else if (k < g.pt + g.pd)          pos = ps_bot + (k - g.pt) * Wp + g.pl + a;
+                else                               pos = ps_mid + a * LR + (k - g.pt - g.pd);
+                ps[pos] = buf[base + a * step];
+            }
+            const int ncorner = part == 0 ? (g.pt + g.pd) * LR : 0;
+            for (int idx = lane; idx < ncorner; idx += 64) {
+                const int ci = idx / LR, cj = idx - ci * LR;
+                const int i = ci < g.pt ? ci : n + ci, j = cj < g.pl ? cj : n + cj;
+                const int s = cubepad_src(f, i, j, g);
+                const int sf = s / nn, rem = s - sf * nn, row = rem / n;
+                ps[ci < g.pt ? i * Wp + j : ps_bot + (ci - g.pt) * Wp + j] = buf[lds_of(sf, row, rem - row * n)];
+            }
+        }
+        __syncthreads();
+        {
+            const int nchunks = (head + plane_elems + E - 1) >> LOG_E;
+            const int top_end = min((rowA + E - 1) >> LOG_E, nchunks);                       // run_begin(0)
+            const int bot_begin = max(((n - 1) * Wp + rowA + n) >> LOG_E, top_end);          // run_end(n - 1)
+            const int n_tb = top_end + (nchunks - bot_begin);
+            const int n_slow = n_tb + (n - 1) * maxc;
+            const int s0 = part * n_slow / parts, s1 = (part + 1) * n_slow / parts;
+            for (int s = s0 + lane; s < s1; s += 64) {
+                int ch;
+                if (s < top_end) ch = s;
+                else if (s < n_tb) ch = bot_begin + (s - top_end);
+                else {
+                    const int m = s - n_tb;
+                    const int rr = div_by(m, maxc, rcp_maxc);
+                    const int lo = max((rr * Wp + rowA + n) >> LOG_E, top_end);              // run_end(rr)
+                    const int hi = min(((rr + 1) * Wp + rowA + E - 1) >> LOG_E, bot_begin);  // run_begin(rr + 1)
+                    ch = lo + (m - rr * maxc);
+                    if (ch >= hi) continue;
+                }
+                const int q0 = ch * E - head;
+                int iA, jA;
+                if (q0 < 0) { iA = -1; jA = q0 + Wp; }
+                else        { iA = div_by(q0, Wp, rcp_wp); jA = q0 - iA * Wp; }
+                const int a = iA - g.pt;
+                const bool rowc = a >= 0 && a < n;
+                const bool q0c = rowc && jA >= g.pl && jA < g.pl + n;
+                const int cpos = a < 0 ? 0 : (a >= n ? nn : a * n + min(max(jA - g.pl, 0), n));
+                const int eA = q0c ? min(E, g.pl + n - jA) : 0;
+                const int aB = q0c ? a + 1 : (a < 0 ? 0 : (rowc ? (jA < g.pl ? a : a + 1) : n));
+                const int eB = aB < n ? min(max((g.pt + aB) * Wp + g.pl - q0, 0), E) : E;
+                const T* pa = buf + (eA > 0 ? ((f * n + a) * 2 + 1) * E + (E - eA) : 0);     // row a's last eA elements at e = 0 ..
+                const T* pb = buf + (eB < E ? ((f * n + aB) * 2) * E - eB : 0);               // row aB's first elements at e = eB ..
+                const T* pp = ps + (q0 - cpos - eA);
+                T tv[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const T va = pa[e], vb = pb[e], pv = pp[e];
+                    tv[e] = e < eA ? va : (e >= eB ? vb : pv);
+                }
+                unsigned char* ca = c0p + ((size_t)ch << 4);
+                if (q0 >= 0 && q0 + E <= plane_elems) {
+                    cp_u32x4 v;
+                    __builtin_memcpy(&v, tv, 16);
+                    *reinterpret_cast<cp_u32x4*>(ca) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (q0 + e >= 0 && q0 + e < plane_elems) reinterpret_cast<T*>(ca)[e] = tv[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------- NCHW, six padded planes assembled in LDS (round 3)
+// What the timing variants of the two kernels above show (profiles/r03_cubepad_plane.md): HBM rewards ONE linear sweep of
+// whole 128-byte lines and punishes everything else - run chunks that leave holes, holes filled later, even whole lines
+// written sparsely all land at 3-3.5 TB/s where the same structure with a linear store stream reaches 4.8-5 (= a plain
+// copy).  So when the six padded planes of a (cube, channel) fit the 160 KB of LDS (n <= 114 for 2-byte elements, every
+// face of the network from layer1 down), the item is assembled there and written once, linearly:
+//   1  load: every 16-byte chunk of the six input planes (n % E == 0: a chunk never crosses a row) goes to its PADDED
+//      position in LDS - plane f starts at f * PSTRIDE + (its global address & 15), so LDS and global chunks coincide;
+//   2  pads: LDS -> LDS element copies through the affine line table (a pad only ever reads a centre element of another
+//      face - cube_pad.py:114-216 - so the copies need no ordering among themselves); corners through cubepad_src();
+//   3  store: aligned 16-byte LDS reads, aligned 16-byte global stores, plane after plane; the first / last chunk of a
+//      plane that is shared with its neighbours goes element by element.
+// HBM traffic = input + output, every line once.  Bit-exact (pure copy).
+template <int ES>
+__global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned char* __restrict__ x,
+                                                                 unsigned char* __restrict__ y, int C, CubePadGeom g,
+                                                                 int n_items, int pstride_b, float rcp_n, float rcp_cprow,
+                                                                 float rcp_cpf, float rcp_nstrip, float rcp_nchmax) {
+    typedef typename ElemOf<ES>::T T;
+    constexpr int E = 16 / ES;
+    constexpr int LOG_E = E == 16 ? 4 : (E == 8 ? 3 : (E == 4 ? 2 : 1));
+    constexpr int UNR = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+    const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr, LR = g.pl + g.pr;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int nlines = g.pt + g.pd + LR, nstrip = nlines * n, ncorner = (g.pt + g.pd) * LR;
+    const int nn = n * n, HW = Hp * Wp;
+    const int cprow = n >> LOG_E, cpf = n * cprow;           // 16-byte chunks per input row / per input plane
+    const int nchmax = (HW + 2 * E - 2) >> LOG_E;            // chunks a padded plane can overlap
+    int* ltab = reinterpret_cast<int*>(smem6);               // [6][16][sf << 24 | offset in the padded plane, step]
+    unsigned char* planes = smem6 + 768;
+    const int pstride_e = pstride_b / ES;
+    const size_t in_face = (size_t)C * nn, out_face_b = (size_t)C * HW * ES;
+    auto div_by = [](int q, int d, float rcp) -> int {       // exact for 0 <= q < 2^24
+        int r = (int)((float)q * rcp);
+        r -= (r * d > q);
+        r += ((r + 1) * d <= q);
+        return r;
+    };
+    if (tid < 96) {
+        const int f = tid >> 4, k = tid & 15;
+        if (k < nlines) {
+            int i0, j0, di = 0, dj = 0;
+            if (k < g.pt)                      { i0 = k;     j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd)          { i0 = n + k; j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd + g.pl)   { i0 = g.pt;  j0 = k - g.pt - g.pd; di = 1; }
+            else                               { i0 = g.pt;  j0 = n + k - g.pt - g.pd; di = 1; }
+            const int s0 = cubepad_src(f, i0, j0, g), d = cubepad_src(f, i0 + di, j0 + dj, g) - s0;
+            const int sf = s0 / nn, rem = s0 - sf * nn, row0 = rem / n, col0 = rem - row0 * n;
+            ltab[(f * 16 + k) * 2] = (sf << 24) | ((g.pt + row0) * Wp + g.pl + col0);
+            ltab[(f * 16 + k) * 2 + 1] = (d == 1 || d == -1) ? d : (d > 0 ? Wp : -Wp);
+        }
+    }
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int grp = item / C, c = item - grp * C;
+        const T* xc = reinterpret_cast<const T*>(x) + (size_t)grp * 6 * in_face + (size_t)c * nn;
+        unsigned char* yc = y + (size_t)grp * 6 * out_face_b + (size_t)c * HW * ES;
+        const size_t yc_addr = reinterpret_cast<size_t>(yc);
+        auto head_b = [&](int f) -> int { return (int)((yc_addr + (size_t)f * out_face_b) & 15); };   // bytes of chunk 0 before plane f
+        // ---- 1: input chunks to their padded places
+        for (int base = tid; base < 6 * cpf; base += NT * UNR) {
+            cp_u32x4 v[UNR];
+            int lo[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + NT * u;
+                lo[u] = -1;
+                if (idx < 6 * cpf) {
+                    const int f = div_by(idx, cpf, rcp_cpf), rem = idx - f * cpf;
+                    const int r = div_by(rem, cprow, rcp_cprow), k = rem - r * cprow;
+                    __builtin_memcpy(&v[u], xc + (size_t)f * in_face + (unsigned)(r * n + k * E), 16);
+                    lo[u] = f * pstride_b + head_b(f) + ((g.pt + r) * Wp + g.pl + k * E) * ES;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (lo[u] < 0) continue;
+                T* d = reinterpret_cast<T*>(planes + lo[u]);  // element-aligned only: E element stores
+                const cp_u32x4 w = v[u];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if constexpr (ES == 8)      d[e] = (T)(((unsigned long long)w[2 * e + 1] << 32) | w[2 * e]);
+                    else if constexpr (ES == 4) d[e] = (T)w[e];
+                    else if constexpr (ES == 2) d[e] = (T)(w[e >> 1] >> (16 * (e & 1)));
+                    else                        d[e] = (T)(w[e >> 2] >> (8 * (e & 3)));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 2: pads
+        T* pe = reinterpret_cast<T*>(planes);
+        for (int idx = tid; idx < 6 * nstrip; idx += NT) {
+            const int f = div_by(idx, nstrip, rcp_nstrip), rem = idx - f * nstrip;
+            const int k = div_by(rem, n, rcp_n), a = rem - k * n;
+            const int t0 = ltab[(f * 16 + k) * 2], step = ltab[(f * 16 + k) * 2 + 1];
+            const int sf = t0 >> 24;
+            int pos;
+            if (k < g.pt)                      pos = k * Wp + g.pl + a;
+            else if (k < g.pt + g.pd)          pos = (n + k) * Wp + g.pl + a;
+            else if (k < g.pt + g.pd + g.pl)   pos = (g.pt + a) * Wp + (k - g.pt - g.pd);
+            else                               pos = (g.pt + a) * Wp + n + (k - g.pt - g.pd);
+            pe[f * pstride_e + head_b(f) / ES + pos] = pe[sf * pstride_e + head_b(sf) / ES + (t0 & 0xffffff) + a * step];
+        }
+        for (int idx = tid; idx < 6 * ncorner; idx += NT) {
+            const int f = idx / ncorner, rem = idx - f * ncorner;
+            const int ci = rem / LR, cj = rem - ci * LR;
+            const int i = ci < g.pt ? ci : n + ci, j = cj < g.pl ? cj : n + cj;
+            const int s = cubepad_src(f, i, j, g);
+            const int sf = s / nn, r2 = s - sf * nn, row = r2 / n, col = r2 - row * n;
+            pe[f * pstride_e + head_b(f) / ES + i * Wp + j] = pe[sf * pstride_e + head_b(sf) / ES + (g.pt + row) * Wp + g.pl + col];
+        }
+        __syncthreads();
+        // ---- 3: linear store
+        for (int base = tid; base < 6 * nchmax; base += NT * UNR) {
+            cp_u32x4 v[UNR];
+            int fs[UNR], chs[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + NT * u;
+                fs[u] = -1;
+                if (idx < 6 * nchmax) {
+                    const int f = div_by(idx, nchmax, rcp_nchmax), ch = idx - f * nchmax;
+                    if (ch * 16 < head_b(f) + HW * ES) {
+                        fs[u] = f;
+                        chs[u] = ch;
+                        v[u] = *reinterpret_cast<const cp_u32x4*>(planes + f * pstride_b + ch * 16);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (fs[u] < 0) continue;
+                const int hb = head_b(fs[u]);
+                unsigned char* ca = yc + (size_t)fs[u] * out_face_b - hb + (size_t)chs[u] * 16;
+                const int q0 = chs[u] * E - hb / ES;
+                if (q0 >= 0 && q0 + E <= HW) {
+                    *reinterpret_cast<cp_u32x4*>(ca) = v[u];
+                } else {                                     // chunk shared with the neighbouring plane
+                    T tv[E];
+                    __builtin_memcpy(tv, &v[u], 16);
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+                        if (q0 + e >= 0 && q0 + e < HW) reinterpret_cast<T*>(ca)[e] = tv[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
 // ---------------------------------------------------------------- NCHW, small faces: whole cubes through LDS (round 3)
 // Faces whose rows are shorter than a cache line (28x28 / 14x14 / 7x7: layers 2-4 and the ConvLSTM) are where the
 // element-per-lane kernel sits at 0.09-0.16 of the HBM peak (profiles/r02f_hbm_kernels.md): 2-4 byte accesses and one
@@ -284,6 +852,93 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
         // (rows of at least 112 bytes - 56x56 f16 faces: 245 -> 149 us against the element-per-lane kernel, round 3; smaller
         //  faces take the whole-cube kernel above)
         static const int strip_min = []() { const char* e = getenv("CP360_CUBEPAD_STRIP_MIN"); return e ? atoi(e) : 112; }();   // A/B switch
+        static const int strip_v1 = []() { const char* e = getenv("CP360_CUBEPAD_STRIP_V1"); return e ? atoi(e) : 0; }();   // A/B switch
+        constexpr int E = 16 / ES;
+        const int LR = g.pl + g.pr, nlines = g.pt + g.pd + LR;
+        const long long ps_size = (long long)Hp * Wp - (long long)g.n * g.n;
+        const int ps_alloc = (int)((ps_size + 2 * E + E - 1) / E * E);
+        const size_t lds2 = 512 + (size_t)4 * ps_alloc * ES;
+        static const int no_channel = []() { const char* e = getenv("CP360_CUBEPAD_NOCHANNEL"); return e ? atoi(e) : 0; }();   // A/B switch
+        static const int channel_min = []() { const char* e = getenv("CP360_CUBEPAD_CHANNEL_MIN"); return e ? atoi(e) : 96; }();
+        {   // six padded planes assembled in LDS, one linear store stream
+            static const int no_lds6 = []() { const char* e = getenv("CP360_CUBEPAD_NOLDS6"); return e ? atoi(e) : 0; }();   // A/B switch
+            static const int lds6_min = []() { const char* e = getenv("CP360_CUBEPAD_LDS6_MIN"); return e ? atoi(e) : 64; }();
+            const long long items = (long long)(n6 / 6) * C;
+            const long long HW = (long long)Hp * Wp;
+            const long long pstride = ((HW + E) * ES + 15) / 16 * 16;
+            const size_t lds6 = 768 + (size_t)6 * pstride;
+            if (!no_strip && !no_lds6 && P >= 1 && nlines <= 16 && g.n % E == 0 && g.n >= 2 && lds6 <= 160 * 1024 && HW < (1 << 22) &&
+                items >= lds6_min && items < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
+                (reinterpret_cast<size_t>(x) % ES) == 0) {
+                static bool attr6_set = false;
+                if (!attr6_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cubepad_nchw_lds6_kernel<ES>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                        return CP360_ERR_HIP;
+                    attr6_set = true;
+                }
+                static const int force_nt6 = []() { const char* e = getenv("CP360_CUBEPAD_LDS6_NT"); return e ? atoi(e) : 0; }();
+                int per_cu = (int)((size_t)160 * 1024 / lds6);
+                int nt = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
+                if (force_nt6 == 256 || force_nt6 == 512 || force_nt6 == 1024) nt = force_nt6;
+                if (per_cu > 2048 / nt) per_cu = 2048 / nt;
+                long long blocks = items < 256ll * per_cu ? items : 256ll * per_cu;
+                const int cprow = g.n / E, cpf = g.n * cprow, nstrip = nlines * g.n, nchmax = (int)((HW + 2 * E - 2) / E);
+                hipLaunchKernelGGL((cubepad_nchw_lds6_kernel<ES>), dim3((unsigned)blocks), dim3(nt), lds6, st,
+                                   (const unsigned char*)x, (unsigned char*)y, C, g, (int)items, (int)pstride, 1.0f / (float)g.n,
+                                   1.0f / (float)cprow, 1.0f / (float)cpf, 1.0f / (float)(nstrip > 0 ? nstrip : 1),
+                                   1.0f / (float)nchmax);
+                CP360_CHECK_HIP();
+                return CP360_OK;
+            }
+        }
+        {   // every input byte once: (cube, channel) items
+            const long long items = (long long)(n6 / 6) * C;
+            const size_t lds3 = 768 + ((size_t)E + (size_t)12 * g.n * E + (size_t)12 * P * g.n + (size_t)6 * ps_alloc + 2 * E) * ES;
+            if (!no_strip && !strip_v1 && !no_channel && P >= 1 && P <= E && g.n * ES >= strip_min && nlines <= 16 &&
+                g.n >= 2 * E + LR && g.n >= 2 * P && lds3 <= 160 * 1024 && (long long)Hp * Wp < (1 << 22) && items >= channel_min &&
+                items < (1ll << 31) && (long long)g.n * g.n < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
+                (reinterpret_cast<size_t>(x) % ES) == 0) {
+                static bool attr_set = false;                // (per element size: launch_nchw<T> is one instance per T)
+                if (!attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cubepad_nchw_channel_kernel<ES>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                        return CP360_ERR_HIP;
+                    attr_set = true;
+                }
+                // one wave per face while that gives >= 12 waves per CU, two (768 threads) for few / large items
+                static const int force_nt = []() { const char* e = getenv("CP360_CUBEPAD_CHANNEL_NT"); return e ? atoi(e) : 0; }();
+                int nt = items >= 512 ? 384 : 768;
+                if (force_nt == 384 || force_nt == 768) nt = force_nt;
+                int per_cu = (int)((size_t)160 * 1024 / lds3);
+                if (per_cu > 2048 / nt) per_cu = 2048 / nt;
+                if (per_cu < 1) per_cu = 1;
+                long long blocks = items < 256ll * per_cu ? items : 256ll * per_cu;
+                const int cpr = g.n / E + 1, maxc = (LR + 2 * E - 2) / E;
+                int rbw = 64 * 8 / cpr;                      // rows per block: one 8-deep body of run chunks per wave
+                if (rbw < 4) rbw = 4;
+                hipLaunchKernelGGL((cubepad_nchw_channel_kernel<ES>), dim3((unsigned)blocks), dim3(nt), lds3, st,
+                                   (const unsigned char*)x, (unsigned char*)y, C, g, (int)items, 1.0f / (float)Wp,
+                                   1.0f / (float)g.n, 1.0f / (float)cpr, maxc, 1.0f / (float)maxc, P, ps_alloc, rbw);
+                CP360_CHECK_HIP();
+                return CP360_OK;
+            }
+        }
+        if (!no_strip && !strip_v1 && P >= 1 && g.n * ES >= strip_min && nlines <= 16 && g.n >= 2 * E + LR && lds2 <= 64 * 1024 &&
+            (long long)Hp * Wp < (1 << 22) && (long long)6 * C * g.n * g.n < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
+            (reinterpret_cast<size_t>(x) % ES) == 0) {
+            const long long items = (long long)planes * 6;
+            long long blocks = (items + 3) / 4;
+            if (blocks > 256 * 32) blocks = 256 * 32;
+            const int cpr = g.n / E + 1, dq = 64 / cpr, dm = 64 - dq * cpr;
+            const int maxc = (LR + 2 * E - 2) / E;
+            hipLaunchKernelGGL((cubepad_nchw_plane_kernel<ES>), dim3((unsigned)blocks), dim3(256), lds2, st,
+                               (const unsigned char*)x, (unsigned char*)y, C, g, (int)items, (long long)n6 * C * g.n * g.n,
+                               1.0f / (float)Wp, 1.0f / (float)g.n, 1.0f / (float)cpr, dq, dm, maxc, 1.0f / (float)maxc, ps_alloc,
+                               std::max(4, 256 / cpr));
+            CP360_CHECK_HIP();
+            return CP360_OK;
+        }
         if (!no_strip && P >= 1 && P <= g.n && g.n * ES >= strip_min && lds <= 64 * 1024 && (long long)Hp * Wp < (1 << 22) &&
             (reinterpret_cast<size_t>(y) % ES) == 0) {
             const long long items = (long long)planes * 6;
