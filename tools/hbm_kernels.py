@@ -78,7 +78,7 @@ def main():
         8 * 3 * (1080 * 2160 + 2 * 1080 * 2048 + 1024 * 2048))
     # ---- K2 standalone CubePad
     for (C, n, p, dt, lab) in ((3, 224, 3, torch.float32, 'f32'), (64, 112, 1, h16, 'f16'), (64, 56, 1, h16, 'f16'),
-                               (256, 14, 1, h16, 'f16')):
+                               (256, 56, 1, h16, 'f16'), (128, 28, 1, h16, 'f16'), (256, 14, 1, h16, 'f16')):
         x = torch.randn((n6, C, n, n), device=dev).to(dt)
         pad = CubePad(p)
         s = x.element_size()
