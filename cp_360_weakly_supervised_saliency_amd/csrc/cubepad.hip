@@ -604,19 +604,23 @@ __global__ __launch_bounds__(768) void cubepad_nchw_channel_kernel(const unsigne
 // whole 128-byte lines and punishes everything else - run chunks that leave holes, holes filled later, even whole lines
 // written sparsely all land at 3-3.5 TB/s where the same structure with a linear store stream reaches 4.8-5 (= a plain
 // copy).  So when the six padded planes of a (cube, channel) fit the 160 KB of LDS (n <= 114 for 2-byte elements, every
-// face of the network from layer1 down), the item is assembled there and written once, linearly:
-//   1  load: every 16-byte chunk of the six input planes (n % E == 0: a chunk never crosses a row) goes to its PADDED
-//      position in LDS - plane f starts at f * PSTRIDE + (its global address & 15), so LDS and global chunks coincide;
+// face of the network from layer1 down), the item is assembled there and written once, linearly.  An item is (cube,
+// channels c0 .. c0 + CH - 1): per face its input is CH * n^2 contiguous elements, its output CH * Hp * Wp contiguous
+// elements (CH = 1 for the large faces; small faces take several channels so that an item is worth its three barriers):
+//   1  load: every 16-byte chunk of the six input ranges goes to its PADDED position in LDS - face f's CH padded planes
+//      start at f * PSTRIDE + (their global address & 15), so LDS and global chunks coincide; a chunk that runs over a row
+//      end (n % E != 0) continues pl + pr elements later, over a plane end (pt + pd) * Wp more;
 //   2  pads: LDS -> LDS element copies through the affine line table (a pad only ever reads a centre element of another
 //      face - cube_pad.py:114-216 - so the copies need no ordering among themselves); corners through cubepad_src();
-//   3  store: aligned 16-byte LDS reads, aligned 16-byte global stores, plane after plane; the first / last chunk of a
-//      plane that is shared with its neighbours goes element by element.
+//   3  store: aligned 16-byte LDS reads, aligned 16-byte global stores, face after face; the first / last chunk of a
+//      range that is shared with its neighbours goes element by element.
 // HBM traffic = input + output, every line once.  Bit-exact (pure copy).
 template <int ES>
 __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned char* __restrict__ x,
                                                                  unsigned char* __restrict__ y, int C, CubePadGeom g,
-                                                                 int n_items, int pstride_b, float rcp_n, float rcp_cprow,
-                                                                 float rcp_cpf, float rcp_nstrip, float rcp_nchmax) {
+                                                                 int CH, int ranges, int n_items, int pstride_b, float rcp_n,
+                                                                 float rcp_nn, float rcp_cpf, float rcp_nstrip,
+                                                                 float rcp_chstrip, float rcp_nchmax) {
     typedef typename ElemOf<ES>::T T;
     constexpr int E = 16 / ES;
     constexpr int LOG_E = E == 16 ? 4 : (E == 8 ? 3 : (E == 4 ? 2 : 1));
@@ -626,8 +630,9 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
     const int tid = threadIdx.x, NT = blockDim.x;
     const int nlines = g.pt + g.pd + LR, nstrip = nlines * n, ncorner = (g.pt + g.pd) * LR;
     const int nn = n * n, HW = Hp * Wp;
-    const int cprow = n >> LOG_E, cpf = n * cprow;           // 16-byte chunks per input row / per input plane
-    const int nchmax = (HW + 2 * E - 2) >> LOG_E;            // chunks a padded plane can overlap
+    const int in_reg = CH * nn, out_reg = CH * HW;           // elements of a face's input / output range
+    const int cpf = (in_reg + E - 1) >> LOG_E;               // 16-byte chunks per input range (the last one may be shifted back)
+    const int nchmax = (out_reg + 2 * E - 2) >> LOG_E;       // chunks an output range can overlap
     int* ltab = reinterpret_cast<int*>(smem6);               // [6][16][sf << 24 | offset in the padded plane, step]
     unsigned char* planes = smem6 + 768;
     const int pstride_e = pstride_b / ES;
@@ -646,31 +651,35 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
             else if (k < g.pt + g.pd)          { i0 = n + k; j0 = g.pl; dj = 1; }
             else if (k < g.pt + g.pd + g.pl)   { i0 = g.pt;  j0 = k - g.pt - g.pd; di = 1; }
             else                               { i0 = g.pt;  j0 = n + k - g.pt - g.pd; di = 1; }
-            const int s0 = cubepad_src(f, i0, j0, g), d = cubepad_src(f, i0 + di, j0 + dj, g) - s0;
+            const int s0 = cubepad_src(f, i0, j0, g), d = n > 1 ? cubepad_src(f, i0 + di, j0 + dj, g) - s0 : 0;
             const int sf = s0 / nn, rem = s0 - sf * nn, row0 = rem / n, col0 = rem - row0 * n;
             ltab[(f * 16 + k) * 2] = (sf << 24) | ((g.pt + row0) * Wp + g.pl + col0);
             ltab[(f * 16 + k) * 2 + 1] = (d == 1 || d == -1) ? d : (d > 0 ? Wp : -Wp);
         }
     }
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int grp = item / C, c = item - grp * C;
-        const T* xc = reinterpret_cast<const T*>(x) + (size_t)grp * 6 * in_face + (size_t)c * nn;
-        unsigned char* yc = y + (size_t)grp * 6 * out_face_b + (size_t)c * HW * ES;
+        const int grp = item / ranges, c0 = (item - grp * ranges) * CH;
+        const T* xc = reinterpret_cast<const T*>(x) + (size_t)grp * 6 * in_face + (size_t)c0 * nn;
+        unsigned char* yc = y + (size_t)grp * 6 * out_face_b + (size_t)c0 * HW * ES;
         const size_t yc_addr = reinterpret_cast<size_t>(yc);
-        auto head_b = [&](int f) -> int { return (int)((yc_addr + (size_t)f * out_face_b) & 15); };   // bytes of chunk 0 before plane f
+        auto head_b = [&](int f) -> int { return (int)((yc_addr + (size_t)f * out_face_b) & 15); };   // bytes of chunk 0 before face f's range
         // ---- 1: input chunks to their padded places
         for (int base = tid; base < 6 * cpf; base += NT * UNR) {
             cp_u32x4 v[UNR];
-            int lo[UNR];
+            int lo[UNR], wrap_at[UNR], wrap_add[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int idx = base + NT * u;
                 lo[u] = -1;
                 if (idx < 6 * cpf) {
-                    const int f = div_by(idx, cpf, rcp_cpf), rem = idx - f * cpf;
-                    const int r = div_by(rem, cprow, rcp_cprow), k = rem - r * cprow;
-                    __builtin_memcpy(&v[u], xc + (size_t)f * in_face + (unsigned)(r * n + k * E), 16);
-                    lo[u] = f * pstride_b + head_b(f) + ((g.pt + r) * Wp + g.pl + k * E) * ES;
+                    const int f = div_by(idx, cpf, rcp_cpf), ck = idx - f * cpf;
+                    const int t0 = min(ck * E, in_reg - E);               // first element (last chunk: shifted back, rewrites equal values)
+                    const int cc = div_by(t0, nn, rcp_nn), rem = t0 - cc * nn;
+                    const int r = div_by(rem, n, rcp_n), col = rem - r * n;
+                    __builtin_memcpy(&v[u], xc + (size_t)f * in_face + (unsigned)t0, 16);
+                    lo[u] = f * pstride_b + head_b(f) + (cc * HW + (g.pt + r) * Wp + g.pl + col) * ES;
+                    wrap_at[u] = n - col;                                  // elements from here on sit in the next row ..
+                    wrap_add[u] = LR + (r + 1 == n ? (g.pt + g.pd) * Wp : 0);   // .. or the next channel's plane
                 }
             }
 #pragma unroll
@@ -680,18 +689,21 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
                 const cp_u32x4 w = v[u];
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    if constexpr (ES == 8)      d[e] = (T)(((unsigned long long)w[2 * e + 1] << 32) | w[2 * e]);
-                    else if constexpr (ES == 4) d[e] = (T)w[e];
-                    else if constexpr (ES == 2) d[e] = (T)(w[e >> 1] >> (16 * (e & 1)));
-                    else                        d[e] = (T)(w[e >> 2] >> (8 * (e & 3)));
+                    T val;
+                    if constexpr (ES == 8)      val = (T)(((unsigned long long)w[2 * e + 1] << 32) | w[2 * e]);
+                    else if constexpr (ES == 4) val = (T)w[e];
+                    else if constexpr (ES == 2) val = (T)(w[e >> 1] >> (16 * (e & 1)));
+                    else                        val = (T)(w[e >> 2] >> (8 * (e & 3)));
+                    d[e + (e >= wrap_at[u] ? wrap_add[u] : 0)] = val;
                 }
             }
         }
         __syncthreads();
         // ---- 2: pads
         T* pe = reinterpret_cast<T*>(planes);
-        for (int idx = tid; idx < 6 * nstrip; idx += NT) {
-            const int f = div_by(idx, nstrip, rcp_nstrip), rem = idx - f * nstrip;
+        for (int idx = tid; idx < 6 * CH * nstrip; idx += NT) {
+            const int f = div_by(idx, CH * nstrip, rcp_chstrip), r1 = idx - f * CH * nstrip;
+            const int cc = div_by(r1, nstrip, rcp_nstrip), rem = r1 - cc * nstrip;
             const int k = div_by(rem, n, rcp_n), a = rem - k * n;
             const int t0 = ltab[(f * 16 + k) * 2], step = ltab[(f * 16 + k) * 2 + 1];
             const int sf = t0 >> 24;
@@ -700,15 +712,18 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
             else if (k < g.pt + g.pd)          pos = (n + k) * Wp + g.pl + a;
             else if (k < g.pt + g.pd + g.pl)   pos = (g.pt + a) * Wp + (k - g.pt - g.pd);
             else                               pos = (g.pt + a) * Wp + n + (k - g.pt - g.pd);
-            pe[f * pstride_e + head_b(f) / ES + pos] = pe[sf * pstride_e + head_b(sf) / ES + (t0 & 0xffffff) + a * step];
+            pe[f * pstride_e + head_b(f) / ES + cc * HW + pos] =
+                pe[sf * pstride_e + head_b(sf) / ES + cc * HW + (t0 & 0xffffff) + a * step];
         }
-        for (int idx = tid; idx < 6 * ncorner; idx += NT) {
-            const int f = idx / ncorner, rem = idx - f * ncorner;
+        for (int idx = tid; idx < 6 * CH * ncorner; idx += NT) {
+            const int f = idx / (CH * ncorner), r1 = idx - f * CH * ncorner;
+            const int cc = r1 / ncorner, rem = r1 - cc * ncorner;
             const int ci = rem / LR, cj = rem - ci * LR;
             const int i = ci < g.pt ? ci : n + ci, j = cj < g.pl ? cj : n + cj;
             const int s = cubepad_src(f, i, j, g);
             const int sf = s / nn, r2 = s - sf * nn, row = r2 / n, col = r2 - row * n;
-            pe[f * pstride_e + head_b(f) / ES + i * Wp + j] = pe[sf * pstride_e + head_b(sf) / ES + (g.pt + row) * Wp + g.pl + col];
+            pe[f * pstride_e + head_b(f) / ES + cc * HW + i * Wp + j] =
+                pe[sf * pstride_e + head_b(sf) / ES + cc * HW + (g.pt + row) * Wp + g.pl + col];
         }
         __syncthreads();
         // ---- 3: linear store
@@ -721,7 +736,7 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
                 fs[u] = -1;
                 if (idx < 6 * nchmax) {
                     const int f = div_by(idx, nchmax, rcp_nchmax), ch = idx - f * nchmax;
-                    if (ch * 16 < head_b(f) + HW * ES) {
+                    if (ch * 16 < head_b(f) + out_reg * ES) {
                         fs[u] = f;
                         chs[u] = ch;
                         v[u] = *reinterpret_cast<const cp_u32x4*>(planes + f * pstride_b + ch * 16);
@@ -734,14 +749,14 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
                 const int hb = head_b(fs[u]);
                 unsigned char* ca = yc + (size_t)fs[u] * out_face_b - hb + (size_t)chs[u] * 16;
                 const int q0 = chs[u] * E - hb / ES;
-                if (q0 >= 0 && q0 + E <= HW) {
+                if (q0 >= 0 && q0 + E <= out_reg) {
                     *reinterpret_cast<cp_u32x4*>(ca) = v[u];
-                } else {                                     // chunk shared with the neighbouring plane
+                } else {                                     // chunk shared with the neighbouring range
                     T tv[E];
                     __builtin_memcpy(tv, &v[u], 16);
 #pragma unroll
                     for (int e = 0; e < E; ++e)
-                        if (q0 + e >= 0 && q0 + e < HW) reinterpret_cast<T*>(ca)[e] = tv[e];
+                        if (q0 + e >= 0 && q0 + e < out_reg) reinterpret_cast<T*>(ca)[e] = tv[e];
                 }
             }
         }
@@ -819,12 +834,16 @@ template <typename T>
 static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom& g, hipStream_t st) {
     const int Wp = g.n + g.pl + g.pr;
     const int planes = (n6 / 6) * C;
-    {   // small faces: whole cubes through LDS.  CH channels per item: the largest divisor-free choice whose input fits
-        // ~24 KiB and whose per-face input / output ranges are whole 16-byte chunks at 16-byte aligned addresses
+    // small faces: whole cubes through LDS.  CH channels per item: the largest divisor-free choice whose input fits
+    // ~24 KiB and whose per-face input / output ranges are whole 16-byte chunks at 16-byte aligned addresses.  Measured
+    // against the lds6 kernel (profiles/r03zz_hbm_kernels.md): better up to 14x14 faces (29 / 12 us against 35 / 15 us
+    // on [384,256,14,14] f16 / the ConvLSTM's [24,2000,7,7] f32), worse at 28x28 (59 against 42 us): it goes first for
+    // n <= 16 and stays the fallback up to 32.
+    auto try_cube = [&](int max_n) -> int {
         constexpr int ES = (int)sizeof(T);
         const int nn = g.n * g.n, HW = (g.n + g.pt + g.pd) * Wp;
         static const int no_cube = []() { const char* e = getenv("CP360_CUBEPAD_NOCUBE"); return e ? atoi(e) : 0; }();   // A/B switch
-        if (!no_cube && g.n <= 32 && HW <= 1444 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
+        if (!no_cube && g.n <= max_n && HW <= 1444 && (reinterpret_cast<size_t>(x) & 15) == 0 && (reinterpret_cast<size_t>(y) & 15) == 0) {
             int CH = 0;
             for (int ch = 1; ch <= C && (size_t)6 * ch * nn * ES <= 24 * 1024; ++ch)
                 if (C % ch == 0 && (ch * nn * ES) % 16 == 0 && (ch * HW * ES) % 16 == 0) CH = ch;
@@ -839,7 +858,9 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
                 return CP360_OK;
             }
         }
-    }
+        return 1;                                            // not taken
+    };
+    if (int r = try_cube(16); r <= 0) return r;
     {   // strip kernel: pads of at most 4 (every pad of the network is 1 or 3), strips within the 64 KiB LDS default
         const int P = max(max(g.pl, g.pr), max(g.pt, g.pd));
         constexpr int ES = (int)sizeof(T);
@@ -863,12 +884,21 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
         {   // six padded planes assembled in LDS, one linear store stream
             static const int no_lds6 = []() { const char* e = getenv("CP360_CUBEPAD_NOLDS6"); return e ? atoi(e) : 0; }();   // A/B switch
             static const int lds6_min = []() { const char* e = getenv("CP360_CUBEPAD_LDS6_MIN"); return e ? atoi(e) : 64; }();
-            const long long items = (long long)(n6 / 6) * C;
-            const long long HW = (long long)Hp * Wp;
-            const long long pstride = ((HW + E) * ES + 15) / 16 * 16;
+            const long long HW = (long long)Hp * Wp, nn = (long long)g.n * g.n;
+            // channels per item: one for faces whose six planes fill the LDS; for small faces the largest divisor of C that
+            // keeps the six ranges within ~40 KB (>= 4 workgroups per CU) and leaves >= 512 items
+            int CH = 1;
+            for (int ch = 2; ch <= C && ch <= 64; ++ch) {
+                if (C % ch) continue;
+                const long long ps = ((ch * HW + E) * ES + 15) / 16 * 16;
+                if (768 + 6 * ps > 40 * 1024 || (long long)(n6 / 6) * (C / ch) < 512) break;
+                CH = ch;
+            }
+            const long long items = (long long)(n6 / 6) * (C / CH);
+            const long long pstride = ((CH * HW + E) * ES + 15) / 16 * 16;
             const size_t lds6 = 768 + (size_t)6 * pstride;
-            if (!no_strip && !no_lds6 && P >= 1 && nlines <= 16 && g.n % E == 0 && g.n >= 2 && lds6 <= 160 * 1024 && HW < (1 << 22) &&
-                items >= lds6_min && items < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
+            if (!no_strip && !no_lds6 && P >= 1 && nlines <= 16 && g.n >= E && CH * nn >= E && lds6 <= 160 * 1024 &&
+                CH * HW < (1 << 22) && items >= lds6_min && items < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
                 (reinterpret_cast<size_t>(x) % ES) == 0) {
                 static bool attr6_set = false;
                 if (!attr6_set) {
@@ -883,15 +913,17 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
                 if (force_nt6 == 256 || force_nt6 == 512 || force_nt6 == 1024) nt = force_nt6;
                 if (per_cu > 2048 / nt) per_cu = 2048 / nt;
                 long long blocks = items < 256ll * per_cu ? items : 256ll * per_cu;
-                const int cprow = g.n / E, cpf = g.n * cprow, nstrip = nlines * g.n, nchmax = (int)((HW + 2 * E - 2) / E);
+                const int nstrip = nlines * g.n;
+                const int cpf = (int)((CH * nn + E - 1) / E), nchmax = (int)((CH * HW + 2 * E - 2) / E);
                 hipLaunchKernelGGL((cubepad_nchw_lds6_kernel<ES>), dim3((unsigned)blocks), dim3(nt), lds6, st,
-                                   (const unsigned char*)x, (unsigned char*)y, C, g, (int)items, (int)pstride, 1.0f / (float)g.n,
-                                   1.0f / (float)cprow, 1.0f / (float)cpf, 1.0f / (float)(nstrip > 0 ? nstrip : 1),
-                                   1.0f / (float)nchmax);
+                                   (const unsigned char*)x, (unsigned char*)y, C, g, CH, C / CH, (int)items, (int)pstride,
+                                   1.0f / (float)g.n, 1.0f / (float)nn, 1.0f / (float)cpf, 1.0f / (float)(nstrip > 0 ? nstrip : 1),
+                                   1.0f / (float)(CH * nstrip > 0 ? CH * nstrip : 1), 1.0f / (float)nchmax);
                 CP360_CHECK_HIP();
                 return CP360_OK;
             }
         }
+        if (int r = try_cube(32); r <= 0) return r;
         {   // every input byte once: (cube, channel) items
             const long long items = (long long)(n6 / 6) * C;
             const size_t lds3 = 768 + ((size_t)E + (size_t)12 * g.n * E + (size_t)12 * P * g.n + (size_t)6 * ps_alloc + 2 * E) * ES;
