@@ -765,6 +765,178 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
 }
 
 
+// ---------------------------------------------------------------- NCHW, planes larger than the LDS: row bands (round 3)
+// The lds6 idea for planes that do not fit (224x224 f32, 256x256 f16): an item is a band of R padded rows of one
+// (cube, channel, face) plane - a contiguous output range - assembled in LDS and written as one linear store stream:
+//   1  the band's centre rows: 16-byte chunks of the contiguous input rows to their padded places (a chunk that runs over
+//      a row end continues pl + pr elements later);
+//   2  its pads straight from the neighbouring faces in global memory through the affine line table (base + a * step per
+//      strip line; a column strip costs one 128-byte line per row - the read amplification the channel kernel avoids,
+//      ~1.2x at 896-byte rows - but nothing is written twice or out of order); corners through cubepad_src();
+//   3  aligned 16-byte LDS reads -> aligned 16-byte global stores; the chunk a band shares with the previous / next band
+//      goes element by element.
+// Items are ordered (plane, face, band): the workgroups running at any time work on neighbouring bands.  Bit-exact.
+template <int ES>
+__global__ __launch_bounds__(256) void cubepad_nchw_band_kernel(const unsigned char* __restrict__ x,
+                                                                unsigned char* __restrict__ y, int C, CubePadGeom g,
+                                                                int n_items, int nb, int R, float rcp_n, float rcp_wp,
+                                                                float rcp_lr) {
+    typedef typename ElemOf<ES>::T T;
+    constexpr int E = 16 / ES;
+    constexpr int LOG_E = E == 16 ? 4 : (E == 8 ? 3 : (E == 4 ? 2 : 1));
+    constexpr int UNR = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+    const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr, LR = g.pl + g.pr;
+    const int tid = threadIdx.x;
+    const int nlines = g.pt + g.pd + LR;
+    const int nn = n * n, HW = Hp * Wp;
+    const int in_face = C * nn;                              // (6 * in_face < 2^31: launcher)
+    int* ltab = reinterpret_cast<int*>(smemb);               // [6][16][element offset from the cube's channel plane 0, step]
+    unsigned char* band = smemb + 768;
+    auto div_by = [](int q, int d, float rcp) -> int {       // exact for 0 <= q < 2^24
+        int r = (int)((float)q * rcp);
+        r -= (r * d > q);
+        r += ((r + 1) * d <= q);
+        return r;
+    };
+    if (tid < 96) {
+        const int f = tid >> 4, k = tid & 15;
+        if (k < nlines) {
+            int i0, j0, di = 0, dj = 0;
+            if (k < g.pt)                      { i0 = k;     j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd)          { i0 = n + k; j0 = g.pl; dj = 1; }
+            else if (k < g.pt + g.pd + g.pl)   { i0 = g.pt;  j0 = k - g.pt - g.pd; di = 1; }
+            else                               { i0 = g.pt;  j0 = n + k - g.pt - g.pd; di = 1; }
+            const int s0 = cubepad_src(f, i0, j0, g), s1 = cubepad_src(f, i0 + di, j0 + dj, g);
+            const int sf = s0 / nn;
+            ltab[(f * 16 + k) * 2] = sf * in_face + (s0 - sf * nn);
+            ltab[(f * 16 + k) * 2 + 1] = s1 - s0;
+        }
+    }
+    __syncthreads();
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int plane = item / (6 * nb), r6 = item - plane * 6 * nb;
+        const int f = r6 / nb, bnd = r6 - f * nb;
+        const int grp = plane / C, c = plane - grp * C;
+        const T* xin = reinterpret_cast<const T*>(x) + (size_t)grp * 6 * in_face + (size_t)c * nn;
+        const T* xf = xin + (size_t)f * in_face;
+        const int i0 = bnd * R, i1 = min(Hp, i0 + R);
+        const int nband = (i1 - i0) * Wp;                    // output elements of the band
+        unsigned char* gb = y + (((size_t)grp * 6 + f) * C + c) * (size_t)HW * ES + (size_t)i0 * Wp * ES;
+        const int hb = (int)(reinterpret_cast<size_t>(gb) & 15), head = hb / ES;
+        T* bp = reinterpret_cast<T*>(band) + head;            // band element q (0 .. nband) lives at bp[q]
+        // ---- 1: centre rows [a0, a1)
+        const int a0 = max(i0, g.pt) - g.pt, a1 = min(i1, g.pt + n) - g.pt;
+        if (a1 > a0) {
+            const int nel = (a1 - a0) * n, nck = (nel + E - 1) >> LOG_E;
+            const T* src = xf + (size_t)a0 * n;
+            const int pos0 = (g.pt + a0 - i0) * Wp + g.pl;
+            for (int base = tid; base < nck; base += 256 * UNR) {
+                cp_u32x4 v[UNR];
+                int lo[UNR], wrap_at[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int ck = base + 256 * u;
+                    lo[u] = -1;
+                    if (ck < nck) {
+                        const int t0 = min(ck * E, nel - E);              // (last chunk shifted back: rewrites equal values)
+                        const int r = div_by(t0, n, rcp_n), col = t0 - r * n;
+                        __builtin_memcpy(&v[u], src + (unsigned)t0, 16);
+                        lo[u] = pos0 + r * Wp + col;
+                        wrap_at[u] = n - col;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (lo[u] < 0) continue;
+                    T* d = bp + lo[u];
+                    const cp_u32x4 w = v[u];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        T val;
+                        if constexpr (ES == 8)      val = (T)(((unsigned long long)w[2 * e + 1] << 32) | w[2 * e]);
+                        else if constexpr (ES == 4) val = (T)w[e];
+                        else if constexpr (ES == 2) val = (T)(w[e >> 1] >> (16 * (e & 1)));
+                        else                        val = (T)(w[e >> 2] >> (8 * (e & 3)));
+                        d[e + (e >= wrap_at[u] ? LR : 0)] = val;
+                    }
+                }
+            }
+            // ---- 2a: left / right pads of those rows
+            const int nside = (a1 - a0) * LR;
+            for (int idx = tid; idx < nside; idx += 256) {
+                const int ra = div_by(idx, LR, rcp_lr), m = idx - ra * LR, a = a0 + ra;
+                const int k = g.pt + g.pd + m;
+                bp[(g.pt + a - i0) * Wp + (m < g.pl ? m : n + m)] = xin[ltab[(f * 16 + k) * 2] + a * ltab[(f * 16 + k) * 2 + 1]];
+            }
+        }
+        // ---- 2b: pad rows of the band (top: i < pt, bottom: i >= pt + n), corners included
+        {
+            const int ntop = max(0, min(i1, g.pt) - i0), b0 = max(i0, g.pt + n), nbot = max(0, i1 - b0);
+            const int ntot = (ntop + nbot) * Wp;
+            for (int base = tid; base < ntot; base += 256 * UNR) {
+                T v[UNR];
+                int pos[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int idx = base + 256 * u;
+                    pos[u] = -1;
+                    if (idx < ntot) {
+                        const int ir = div_by(idx, Wp, rcp_wp), j = idx - ir * Wp;
+                        const int i = ir < ntop ? i0 + ir : b0 + (ir - ntop);
+                        int so;
+                        if (j >= g.pl && j < g.pl + n) {
+                            const int k = i < g.pt ? i : i - n;
+                            so = ltab[(f * 16 + k) * 2] + (j - g.pl) * ltab[(f * 16 + k) * 2 + 1];
+                        } else {
+                            const int s = cubepad_src(f, i, j, g);
+                            const int sf = s / nn;
+                            so = sf * in_face + (s - sf * nn);
+                        }
+                        v[u] = xin[so];
+                        pos[u] = (i - i0) * Wp + j;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (pos[u] >= 0) bp[pos[u]] = v[u];
+            }
+        }
+        __syncthreads();
+        // ---- 3: linear store
+        {
+            const int nch = (head + nband + E - 1) >> LOG_E;
+            unsigned char* c0p = gb - hb;
+            for (int base = tid; base < nch; base += 256 * UNR) {
+                cp_u32x4 v[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int ch = base + 256 * u;
+                    if (ch < nch) v[u] = *reinterpret_cast<const cp_u32x4*>(band + ch * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int ch = base + 256 * u;
+                    if (ch >= nch) continue;
+                    const int q0 = ch * E - head;
+                    unsigned char* ca = c0p + (size_t)ch * 16;
+                    if (q0 >= 0 && q0 + E <= nband) {
+                        *reinterpret_cast<cp_u32x4*>(ca) = v[u];
+                    } else {                                 // chunk shared with the neighbouring band / plane
+                        T tv[E];
+                        __builtin_memcpy(tv, &v[u], 16);
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            if (q0 + e >= 0 && q0 + e < nband) reinterpret_cast<T*>(ca)[e] = tv[e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+
 // ---------------------------------------------------------------- NCHW, small faces: whole cubes through LDS (round 3)
 // Faces whose rows are shorter than a cache line (28x28 / 14x14 / 7x7: layers 2-4 and the ConvLSTM) are where the
 // element-per-lane kernel sits at 0.09-0.16 of the HBM peak (profiles/r02f_hbm_kernels.md): 2-4 byte accesses and one
@@ -924,6 +1096,26 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
             }
         }
         if (int r = try_cube(32); r <= 0) return r;
+        {   // planes larger than the LDS: row bands assembled in LDS, linear stores
+            static const int no_band = []() { const char* e = getenv("CP360_CUBEPAD_NOBAND"); return e ? atoi(e) : 0; }();   // A/B switch
+            static const int band_min_row = []() { const char* e = getenv("CP360_CUBEPAD_BAND_MINROW"); return e ? atoi(e) : 256; }();
+            int R = 16384 / (Wp * ES);                       // ~16 KB of output per item
+            if (R < 2) R = 2;
+            if (R > Hp) R = Hp;
+            const int nb = (Hp + R - 1) / R;
+            const long long items = (long long)planes * 6 * nb;
+            const size_t ldsb = 768 + (size_t)((long long)R * Wp + 2 * E) * ES + 16;
+            if (!no_strip && !no_band && P >= 1 && nlines <= 16 && g.n >= E && g.n * ES >= band_min_row && ldsb <= 64 * 1024 &&
+                (long long)Hp * Wp < (1 << 22) && (long long)6 * C * g.n * g.n < (1ll << 31) && items < (1ll << 31) && LR >= 0 &&
+                (reinterpret_cast<size_t>(y) % ES) == 0 && (reinterpret_cast<size_t>(x) % ES) == 0) {
+                long long blocks = items < 256 * 8 ? items : 256 * 8;
+                hipLaunchKernelGGL((cubepad_nchw_band_kernel<ES>), dim3((unsigned)blocks), dim3(256), ldsb, st,
+                                   (const unsigned char*)x, (unsigned char*)y, C, g, (int)items, nb, R, 1.0f / (float)g.n,
+                                   1.0f / (float)Wp, 1.0f / (float)(LR > 0 ? LR : 1));
+                CP360_CHECK_HIP();
+                return CP360_OK;
+            }
+        }
         {   // every input byte once: (cube, channel) items
             const long long items = (long long)(n6 / 6) * C;
             const size_t lds3 = 768 + ((size_t)E + (size_t)12 * g.n * E + (size_t)12 * P * g.n + (size_t)6 * ps_alloc + 2 * E) * ES;

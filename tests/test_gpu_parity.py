@@ -92,42 +92,36 @@ def test_cubepad_nchw_small_faces_whole_cube_kernel(shape, pad, dtype):
 
 
 def test_cubepad_nchw_randomised_geometry_sweep():
-    """Seeded sweep over the three NCHW kernels' dispatch space (csrc/cubepad.hip launch_nchw: whole-cube kernel for
-    faces <= 32, strip kernel from 112-byte rows, element-per-lane otherwise): random face size, asymmetric pads (each
-    <= n, cube_pad.py:60-70), channel count, element size, 1-2 cubes, and a base pointer offset by a few elements so the
-    16-byte alignment checks see misaligned planes.  Bit-exact against the oracle (cube_pad.py:95-216)."""
-    rng = np.random.RandomState(20260)
-    dts = [torch.uint8, torch.int16, torch.int32, torch.int64]
-    for case in range(60):
-        n = int(rng.choice([1, 2, 3, 5, 7, 8, 14, 16, 28, 31, 32, 33, 56, 57, 64, 112, 113, 130]))
-        pad = [int(min(n, v)) for v in rng.randint(0, 5, size=4)]
-        C = int(rng.randint(1, 24))
-        n6 = 6 * int(rng.randint(1, 3))
-        dt = dts[int(rng.randint(0, 4))]
-        off = int(rng.randint(0, 4))
-        x = rng.randint(0, 120, size=(n6, C, n, n)).astype({torch.uint8: np.uint8, torch.int16: np.int16,
-                                                                torch.int32: np.int32, torch.int64: np.int64}[dt])
-        buf = torch.zeros(x.size + off, dtype=dt, device=DEV)
-        buf[off:] = torch.from_numpy(x).reshape(-1).to(DEV)
-        xt = buf[off:].view(n6, C, n, n)
-        want = o_cubepad.cubepad(x, pad)
-        got = CubePad(pad)(xt).cpu().numpy()
-        assert got.shape == want.shape and np.array_equal(got, want), (case, n, pad, C, n6, dt, off)
-    # enough (cube, channel) items for the read-once kernel (cubepad_nchw_channel_kernel: >= 96 items), 256- and
-    # 1024-thread variants, shared head / tail chunks (odd plane sizes), pads of 0 on some sides
-    for case, (n, pad, C, n6, dt, off) in enumerate([
-            (56, [1, 1, 1, 1], 64, 12, torch.int16, 0), (57, [2, 0, 1, 3], 50, 12, torch.int16, 1),
-            (112, [1, 1, 1, 1], 48, 12, torch.int16, 0), (113, [3, 3, 3, 3], 17, 36, torch.int32, 0),
-            (224, [3, 3, 3, 3], 3, 192, torch.int32, 0), (130, [0, 4, 2, 0], 25, 24, torch.uint8, 3),
-            (40, [1, 2, 0, 1], 33, 18, torch.int64, 0), (64, [4, 4, 4, 4], 16, 36, torch.int32, 2),
-            (256, [1, 1, 1, 1], 16, 36, torch.int16, 0)]):
-        x = rng.randint(0, 120, size=(n6, C, n, n)).astype({torch.uint8: np.uint8, torch.int16: np.int16,
-                                                                torch.int32: np.int32, torch.int64: np.int64}[dt])
-        buf = torch.zeros(x.size + off, dtype=dt, device=DEV)
-        buf[off:] = torch.from_numpy(x).reshape(-1).to(DEV)
-        want = o_cubepad.cubepad(x, pad)
-        got = CubePad(pad)(buf[off:].view(n6, C, n, n)).cpu().numpy()
-        assert got.shape == want.shape and np.array_equal(got, want), ('channel', case, n, pad, C, n6, dt, off)
+    """Seeded sweep over the NCHW kernels' dispatch space (csrc/cubepad.hip launch_nchw: whole-cube kernel for small
+    faces, lds6 when the six padded planes fit the LDS, row bands for long rows, channel / plane / strip kernels and the
+    element-per-lane kernel otherwise): random face size, asymmetric pads (each <= n, cube_pad.py:60-70), channel count,
+    element size, 1-2 cubes, and a base pointer offset by a few elements so the 16-byte alignment checks see misaligned
+    planes; then shapes with enough (cube, channel) items for the read-once kernels, odd plane sizes (chunks shared between
+    planes), pads of 0 on some sides.  Bit-exact against the oracle (cube_pad.py:95-216).  tests/parity_helpers.py."""
+    ph.cubepad_sweep(DEV)
+
+
+@pytest.mark.parametrize('env', [
+    {'CP360_CUBEPAD_NOLDS6': '1', 'CP360_CUBEPAD_NOBAND': '1', 'CP360_CUBEPAD_CHANNEL_MIN': '1'},      # channel kernel
+    {'CP360_CUBEPAD_NOLDS6': '1', 'CP360_CUBEPAD_NOBAND': '1', 'CP360_CUBEPAD_NOCHANNEL': '1'},        # plane kernel
+    {'CP360_CUBEPAD_NOLDS6': '1', 'CP360_CUBEPAD_NOBAND': '1', 'CP360_CUBEPAD_STRIP_V1': '1'},         # round-2 strip kernel
+    {'CP360_CUBEPAD_NOLDS6': '1', 'CP360_CUBEPAD_NOCUBE': '1', 'CP360_CUBEPAD_BAND_MINROW': '1'},      # row bands everywhere
+    {'CP360_CUBEPAD_NOCUBE': '1', 'CP360_CUBEPAD_LDS6_MIN': '1'},                                       # lds6 wherever it fits
+    {'CP360_CUBEPAD_ELEMENTWISE': '1', 'CP360_CUBEPAD_NOCUBE': '1'},                                    # element-per-lane kernel
+], ids=['channel', 'plane', 'strip_v1', 'band', 'lds6', 'elementwise'])
+def test_cubepad_nchw_sweep_with_each_kernel_forced(env):
+    """The same sweep with the dispatch pinned to each NCHW kernel through its A/B switch (the switches are read once per
+    process, hence a child process per setting): every kernel is bit-exact on every geometry it accepts, not only on the
+    ones the default dispatch hands it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, '-c', 'from tests import parity_helpers as ph; ph.cubepad_sweep("cuda"); print("SWEEP_OK")'],
+                       cwd=root, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'SWEEP_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_cubepad_nhwc_and_channel_padding():
