@@ -1224,21 +1224,22 @@ extern "C" int cp360_cubepad_nchw(const void* x, void* y, int n6, int C, int n, 
 // A pixel is a contiguous channel vector: the pad is a pixel-granular gather, so
 // every load and store is a full-width (4/8/16-byte per lane) contiguous access.
 // VEC = 32-bit words per lane access.  One "row" of work = one output pixel.
-template <int VEC>
+// IT = index type: unsigned when the vector count fits 32 bits (always, in practice): the three divisions per vector are
+// then 32-bit (the 64-bit form costs more instructions than cubepad_src() itself).
+template <int VEC, typename IT>
 __global__ __launch_bounds__(256) void cubepad_nhwc_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
                                                            int n6, int cw /*words per in pixel*/,
                                                            int cyw /*words per out pixel*/, CubePadGeom g) {
     const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr;
     const int vec_per_pix = cyw / VEC;
-    const long long total = (long long)n6 * Hp * Wp * vec_per_pix;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const long long pix = idx / vec_per_pix;
-        const int v = (int)(idx - pix * vec_per_pix) * VEC;
-        const int j = (int)(pix % Wp);
-        const long long t = pix / Wp;
-        const int i = (int)(t % Hp);
-        const int img = (int)(t / Hp);
+    const IT total = (IT)((long long)n6 * Hp * Wp * vec_per_pix);
+    for (IT idx = (IT)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (IT)gridDim.x * blockDim.x) {
+        const IT pix = idx / (IT)vec_per_pix;
+        const int v = (int)(idx - pix * (IT)vec_per_pix) * VEC;
+        const int j = (int)(pix % (IT)Wp);
+        const IT t = pix / (IT)Wp;
+        const int i = (int)(t % (IT)Hp);
+        const int img = (int)(t / (IT)Hp);
         const int grp = img / 6, f = img - grp * 6;
         const int s = cubepad_src(f, i, j, g);
         const uint32_t* src = x + ((size_t)grp * 6 * n * n + s) * cw + v;
@@ -1252,6 +1253,30 @@ __global__ __launch_bounds__(256) void cubepad_nhwc_kernel(const uint32_t* __res
         } else {
             *dst = (v < cw) ? *src : 0u;
         }
+    }
+}
+
+// Narrow pixels (1-4 words: the 3-channel f32 input of conv1 is 3): a thread owns a whole output pixel - one
+// cubepad_src() and one set of 32-bit divisions per pixel instead of per word, one CW-word load and one store.
+template <int CW>
+__global__ __launch_bounds__(256) void cubepad_nhwc_px_kernel(const uint32_t* __restrict__ x, uint32_t* __restrict__ y,
+                                                              unsigned total_px, int cyw, CubePadGeom g) {
+    const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr;
+    for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < total_px; pix += gridDim.x * blockDim.x) {
+        const int j = (int)(pix % (unsigned)Wp);
+        const unsigned t = pix / (unsigned)Wp;
+        const int i = (int)(t % (unsigned)Hp);
+        const int img = (int)(t / (unsigned)Hp);
+        const int grp = img / 6, f = img - grp * 6;
+        const int s = cubepad_src(f, i, j, g);
+        const uint32_t* src = x + ((size_t)grp * 6 * n * n + s) * CW;
+        uint32_t* dst = y + (size_t)pix * cyw;
+        uint32_t w[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) w[e] = src[e];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) dst[e] = w[e];
+        for (int e = CW; e < cyw; ++e) dst[e] = 0u;
     }
 }
 
@@ -1275,12 +1300,24 @@ extern "C" int cp360_cubepad_nhwc(const void* x, void* y, int n6, int C, int Cy,
     if (blocks < 1) blocks = 1;
     const uint32_t* xi = (const uint32_t*)x;
     uint32_t* yo = (uint32_t*)y;
-    if (vec == 4)
-        hipLaunchKernelGGL((cubepad_nhwc_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, st, xi, yo, n6, cw, cyw, g);
-    else if (vec == 2)
-        hipLaunchKernelGGL((cubepad_nhwc_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, xi, yo, n6, cw, cyw, g);
-    else
-        hipLaunchKernelGGL((cubepad_nhwc_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, xi, yo, n6, cw, cyw, g);
+    static const int no_px = []() { const char* e = getenv("CP360_CUBEPAD_NHWC_NOPX"); return e ? atoi(e) : 0; }();   // A/B switch
+    const long long total_px = (long long)n6 * Hp * Wp;
+    if (!no_px && vec < 4 && cw <= 4 && cyw <= 8 && total_px < (1ll << 32)) {      // narrow pixels: a thread per pixel
+        long long pb = (total_px + 255) / 256;
+        if (pb > 256 * 16) pb = 256 * 16;
+#define CP360_PX(CWV) hipLaunchKernelGGL((cubepad_nhwc_px_kernel<CWV>), dim3((unsigned)pb), dim3(256), 0, st, xi, yo, (unsigned)total_px, cyw, g)
+        if (cw == 1) CP360_PX(1); else if (cw == 2) CP360_PX(2); else if (cw == 3) CP360_PX(3); else CP360_PX(4);
+#undef CP360_PX
+        CP360_CHECK_HIP();
+        return CP360_OK;
+    }
+    const bool i32 = total < (1ll << 32) - (long long)blocks * 256;      // (the grid-stride increment must not wrap either)
+#define CP360_NHWC(V) do { if (i32) hipLaunchKernelGGL((cubepad_nhwc_kernel<V, unsigned>), dim3((unsigned)blocks), dim3(256), 0, st, xi, yo, n6, cw, cyw, g); \
+                           else hipLaunchKernelGGL((cubepad_nhwc_kernel<V, long long>), dim3((unsigned)blocks), dim3(256), 0, st, xi, yo, n6, cw, cyw, g); } while (0)
+    if (vec == 4) CP360_NHWC(4);
+    else if (vec == 2) CP360_NHWC(2);
+    else CP360_NHWC(1);
+#undef CP360_NHWC
     CP360_CHECK_HIP();
     return CP360_OK;
 }

@@ -137,6 +137,29 @@ def test_cubepad_nhwc_and_channel_padding():
     assert np.array_equal(CubePad(1)(cl).cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('C,dtype,c_out,n,pad', [
+    (3, torch.float32, None, 224, 3),        # conv1's input pad in NHWC (pixel-per-thread kernel, 3 words)
+    (3, torch.float32, 4, 57, [2, 0, 1, 3]), # ... with the channel padding 3 -> 4 of the fused path, asymmetric pads
+    (1, torch.float32, None, 9, 1), (2, torch.float32, 8, 16, 2), (4, torch.int32, None, 14, 1),
+    (6, torch.float16, None, 28, 1),         # 3 words of 2-byte channels
+    (8, torch.bfloat16, None, 28, 1),        # 4 words: the 16-byte vector kernel
+    (64, torch.float16, None, 56, 1), (7, torch.float32, None, 33, [1, 2, 3, 0]),
+])
+def test_cubepad_nhwc_pixel_widths(C, dtype, c_out, n, pad):
+    """csrc/cubepad.hip NHWC kernels (a thread per pixel for 1-4 word pixels, 4 / 8 / 16-byte vectors with 32-bit index
+    arithmetic otherwise), optional zero-filled channel padding: bit-exact against the oracle (cube_pad.py:95-216)."""
+    x = hashrng.integers(91, (12, C, n, n), 0, 250).astype(np.float64)
+    xt = torch.from_numpy(x).to(dtype)
+    bits = {2: torch.int16, 4: torch.int32}[xt.element_size()]
+    want = o_cubepad.cubepad(xt.view(bits).numpy(), pad)                       # NCHW bit patterns
+    xn = xt.permute(0, 2, 3, 1).contiguous().to(DEV)
+    got = ops.cubepad_nhwc(xn, pad, c_out=c_out) if c_out else ops.cubepad_nhwc(xn, pad)
+    g = got.cpu().view(bits).numpy()
+    assert np.array_equal(g[..., :C].transpose(0, 3, 1, 2), want)
+    if c_out:
+        assert g.shape[-1] == c_out and not g[..., C:].any()
+
+
 def test_cubepad_errors():
     with pytest.raises(ValueError):
         CubePad(1)(torch.zeros(5, 2, 4, 4, device=DEV))
