@@ -1,6 +1,18 @@
 // K2: CubePad as stand-alone HIP kernels (NCHW for the reference's module boundary,
 // NHWC for the fused pipeline) + the host-side table export.
 // Semantics: model/cube_pad.py:28-42,95-216 (see common.h: cubepad_src).
+//
+// NCHW kernels, in the order launch_nchw() tries them (each is bit-exact; A/B switches in launch_nchw; measurements and
+// the reasoning behind the designs: profiles/r03_cubepad_plane.md):
+//   cubepad_nchw_cube_kernel     faces up to 16x16 (fallback up to 32x32): (cube, channel range) items through LDS, the
+//                                CubePad map as a per-workgroup table
+//   cubepad_nchw_lds6_kernel     the six padded planes of a (cube, channel range) fit the LDS: assembled there, written
+//                                as one linear store stream (the network's 28x28 ... 112x112 faces)
+//   cubepad_nchw_band_kernel     rows of >= 256 bytes, planes larger than the LDS: the same per row band of one plane
+//   cubepad_nchw_channel_kernel  (cube, channel) items, every input byte read once, pads from LDS captures
+//   cubepad_nchw_plane_kernel    (plane, face) items, runs + pad stream
+//   cubepad_nchw_strip_kernel    round-2 form of the plane kernel
+//   cubepad_nchw_kernel          element per lane, any geometry
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -1106,7 +1118,7 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
             const long long items = (long long)planes * 6 * nb;
             const size_t ldsb = 768 + (size_t)((long long)R * Wp + 2 * E) * ES + 16;
             if (!no_strip && !no_band && P >= 1 && nlines <= 16 && g.n >= E && g.n * ES >= band_min_row && ldsb <= 64 * 1024 &&
-                (long long)Hp * Wp < (1 << 22) && (long long)6 * C * g.n * g.n < (1ll << 31) && items < (1ll << 31) && LR >= 0 &&
+                (long long)Hp * Wp < (1 << 22) && (long long)6 * C * g.n * g.n < (1ll << 31) && items < (1ll << 31) &&
                 (reinterpret_cast<size_t>(y) % ES) == 0 && (reinterpret_cast<size_t>(x) % ES) == 0) {
                 long long blocks = items < 256 * 8 ? items : 256 * 8;
                 hipLaunchKernelGGL((cubepad_nchw_band_kernel<ES>), dim3((unsigned)blocks), dim3(256), ldsb, st,
