@@ -16,6 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 
 // ---------------------------------------------------------------- NCHW
 // One workgroup per (group g, channel c): it writes the 6 padded planes of that
@@ -1014,6 +1015,23 @@ __global__ __launch_bounds__(256) void cubepad_nchw_cube_kernel(const unsigned c
     }
 }
 
+// Kernels that take more than the 64 KB default of dynamic LDS: raise the limit once per (kernel instance, device) - a
+// process that drives several GPUs sets it on each (thread-safe: at worst two threads set the same attribute).
+template <auto Kernel>
+static int ensure_big_lds() {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return CP360_ERR_HIP;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return CP360_ERR_HIP;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return CP360_OK;
+}
+
 template <typename T>
 static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom& g, hipStream_t st) {
     const int Wp = g.n + g.pl + g.pr;
@@ -1084,13 +1102,7 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
             if (!no_strip && !no_lds6 && P >= 1 && nlines <= 16 && g.n >= E && CH * nn >= E && lds6 <= 160 * 1024 &&
                 CH * HW < (1 << 22) && items >= lds6_min && items < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
                 (reinterpret_cast<size_t>(x) % ES) == 0) {
-                static bool attr6_set = false;
-                if (!attr6_set) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cubepad_nchw_lds6_kernel<ES>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                        return CP360_ERR_HIP;
-                    attr6_set = true;
-                }
+                if (int rc = ensure_big_lds<&cubepad_nchw_lds6_kernel<ES>>()) return rc;
                 static const int force_nt6 = []() { const char* e = getenv("CP360_CUBEPAD_LDS6_NT"); return e ? atoi(e) : 0; }();
                 int per_cu = (int)((size_t)160 * 1024 / lds6);
                 int nt = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
@@ -1135,13 +1147,7 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
                 g.n >= 2 * E + LR && g.n >= 2 * P && lds3 <= 160 * 1024 && (long long)Hp * Wp < (1 << 22) && items >= channel_min &&
                 items < (1ll << 31) && (long long)g.n * g.n < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
                 (reinterpret_cast<size_t>(x) % ES) == 0) {
-                static bool attr_set = false;                // (per element size: launch_nchw<T> is one instance per T)
-                if (!attr_set) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cubepad_nchw_channel_kernel<ES>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                        return CP360_ERR_HIP;
-                    attr_set = true;
-                }
+                if (int rc = ensure_big_lds<&cubepad_nchw_channel_kernel<ES>>()) return rc;
                 // one wave per face while that gives >= 12 waves per CU, two (768 threads) for few / large items
                 static const int force_nt = []() { const char* e = getenv("CP360_CUBEPAD_CHANNEL_NT"); return e ? atoi(e) : 0; }();
                 int nt = items >= 512 ? 384 : 768;
