@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Benchmark of the hot path on N MI355X GPUs of one node (one process per GPU).
 
     python bench.py --gpus 1 --steps K --warmup W
@@ -78,24 +77,50 @@ def cpu_model():
     return 'unknown'
 
 
+def sync(dev):
+    if torch.device(dev).type == 'cuda':
+        torch.cuda.synchronize()
+
+
 def timed(step, warmup, steps, dev, per_rank=False):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
     per_rank: also this rank's own time up to its synchronize, BEFORE the closing barrier (diagnosis of N > 1 runs)."""
     out = None
     for _ in range(warmup):
         out = step()
-    torch.cuda.synchronize()
+    sync(dev)
     cpdist.barrier()
-    torch.cuda.synchronize()
+    sync(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
-    torch.cuda.synchronize()
+    sync(dev)
     mine = time.perf_counter() - t0
     cpdist.barrier()
-    torch.cuda.synchronize()
+    sync(dev)
     total = cpdist.max_over_ranks(time.perf_counter() - t0, dev)
     return ((total, mine) if per_rank else total), out
+
+
+class StubEngine:
+    """--stub-engine: stands in for SaliencyEngine on a box WITHOUT a GPU so that this file's own main() - launcher
+    contract, sharding, the all-gather, max-over-ranks timing, the JSON line - runs under
+    ``torch.distributed.run --nproc-per-node N`` on gloo (tests/test_distributed_cpu.py).  It computes no saliency: a
+    clip's "map" is a fixed function of its frames, so the gathered result can be checked clip for clip.  Its numbers
+    mean nothing and the JSON line says so (``"stub_engine": true``)."""
+
+    def __init__(self, cube_dim, clips, frames):
+        self.B, self.T, self.w = int(clips), int(frames), int(cube_dim) // 32
+        self.static_precision, self.fp16_fallback = 'fp32', False
+
+    def __call__(self, frames):
+        B = frames.shape[0]
+        m = frames.reshape(B, -1).float().mean(dim=1)
+        ramp = torch.arange(2 * self.w * 4 * self.w, dtype=torch.float32).reshape(1, 2 * self.w, 4 * self.w)
+        return m.reshape(B, 1, 1) + ramp / ramp.numel()
+
+    def close(self):
+        pass
 
 
 def roofline_pass(eng, frames, precision, steps=2):
@@ -142,15 +167,67 @@ def roofline_pass(eng, frames, precision, steps=2):
             'avg_launch_ms': round(ms, 4), 'launches_timed': n, 'flops_per_launch': flops}
 
 
+STATIC_GFLOP = {224: 49.05 + 1.20, 256: 64.06 + 1.57, 512: 256.24 + 6.29}     # ResNet-50-cubic + CAM, per frame
+
+
+def stage_split(eng, frames, reps=3):
+    """Where one step's time goes (never inside the timed region): the static stage (K1 + ResNet-50-cubic + CAM), the
+    ConvLSTM window (min / max, T cell updates) and the cube -> equi + channel max, each bracketed by one HIP event pair on
+    the launch stream; median of ``reps`` extra steps.  With it two driver runs on different boxes can be compared stage
+    by stage."""
+    B, T = frames.shape[:2]
+    flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
+    rows = []
+    with torch.no_grad():
+        for _ in range(reps):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            marks = []
+            ev[0].record()
+            eng.static_stage(flat)
+            ev[1].record()
+            eng.runner.stage_events = marks
+            try:
+                eng.temporal_stage()
+            finally:
+                eng.runner.stage_events = None
+            torch.cuda.synchronize()
+            rows.append((ev[0].elapsed_time(ev[1]), marks[0].elapsed_time(marks[1]), marks[1].elapsed_time(marks[2])))
+    med = lambda k: round(float(np.median([r[k] for r in rows])), 3)
+    return {'static': med(0), 'convlstm': med(1), 'c2e': med(2)}
+
+
+def static_roofline(ms_per_step, B, T, cd, precision):
+    """BASELINE config C2 (static path only): algorithmic flops of the stage / the measured time per pass
+    against the MFMA peak of the arithmetic type; the per-launch picture (slowest launch, workgroups per launch) is the
+    tracked timeline of the same command, when one has been collected."""
+    gf = STATIC_GFLOP.get(cd)
+    if gf is None:
+        return None
+    ach = gf * B * T / (ms_per_step * 1e-3) / 1e3
+    r = {'bound': 'mfma', 'kernel': 'static stage: K1 + %d conv launches of ResNet-50-cubic + CAM, %d faces per pass' % (54, 6 * B * T),
+         'achieved': round(ach, 2), 'peak': PEAK[precision], 'unit': 'TFLOP/s', 'frac': round(ach / PEAK[precision], 4),
+         'flops_per_pass': gf * B * T * 1e9, 'traffic': None}
+    tp = os.path.join(REPO, 'profiles', 'c2_static_%s_f%d.json' % (precision, B * T))
+    if os.path.exists(tp):
+        t = json.load(open(tp))
+        r['timeline'] = 'profiles/' + t.get('source', '')
+        r['slowest_launch'] = t.get('slowest_launch')
+        r['launches'] = t.get('launches')
+    return r
+
+
 def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, graph=False, static_only=False,
                  frame_chunk=None, source_hw=None, want_roofline=False, static_precision=None, all_steps=False,
-                 f32_input=False):
-    rs = synth.resnet50_state(seed=1)
-    cs = synth.clstm_state(seed=2)
-    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=B, frames=T, precision=precision, device=dev,
-                         frame_chunk=frame_chunk, source_hw=source_hw, static_precision=static_precision,
-                         return_all_steps=all_steps)
-    del rs, cs
+                 f32_input=False, stub=False, want_split=False):
+    if stub:
+        eng = StubEngine(cd, B, T)
+    else:
+        rs = synth.resnet50_state(seed=1)
+        cs = synth.clstm_state(seed=2)
+        eng = SaliencyEngine(rs, cs, (H, W), cd, clips=B, frames=T, precision=precision, device=dev,
+                             frame_chunk=frame_chunk, source_hw=source_hw, static_precision=static_precision,
+                             return_all_steps=all_steps)
+        del rs, cs
     fh, fw = source_hw if source_hw else (H, W)
     # this rank's clips (global clip id = rank*B + b), resident in HBM before timing
     frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + rank * B + b, T, fh, fw)) for b in range(B)]).to(dev)
@@ -161,9 +238,22 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
     n_clips = world * B
     if graph and not static_only:
         eng.capture(frames)
+    static_graph = None
+    if graph and static_only:
+        # one frame is ~60 launches of a few microseconds each: replay them from a HIP graph
+        flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
+        with torch.no_grad():
+            eng.static_stage(flat)
+            torch.cuda.synchronize()
+            static_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(static_graph):
+                eng.static_stage(flat)
 
     def step():
         if static_only:
+            if static_graph is not None:
+                static_graph.replay()
+                return eng.cam.view(B, -1)[:, :8]
             with torch.no_grad():
                 cam = eng.static_stage(frames.reshape((B * T,) + tuple(frames.shape[2:])))
             return cam.view(B, -1)[:, :8].float()
@@ -179,22 +269,29 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
     res['ms_per_step_per_rank'] = [round(1000.0 * v / steps, 3) for v in cpdist.all_ranks(mine, dev)]
     if not static_only:
         sal = eng(frames)
-        torch.cuda.synchronize()
+        sync(dev)
         cpdist.barrier()
         t0 = time.perf_counter()
         for _ in range(10):
             cpdist.gather_maps(sal, n_clips, rank, world)
-        torch.cuda.synchronize()
+        sync(dev)
         res['allgather_ms'] = round(cpdist.max_over_ranks(time.perf_counter() - t0, dev) * 100.0, 4)
         res['allgather_bytes_per_rank'] = int(sal.numel() * sal.element_size())
         res['map_shape'] = list(out.shape)
-    if want_roofline and not static_only:
+    if want_split and not static_only and not stub:
+        if graph:
+            eng._graph = None
+        res['stage_ms'] = stage_split(eng, frames)
+    if want_roofline and not static_only and not stub:
         if graph:
             eng._graph = None                      # the roofline pass needs eager launches to bracket
         res['roofline'] = roofline_pass(eng, frames, precision)
+    if static_only and not stub:
+        res['roofline'] = static_roofline(res['ms_per_step'], B, T, cd, eng.static_precision)
     res['w'] = eng.w
     res['static_dtype'] = DTYPE[eng.static_precision]
     res['fp16_fallback'] = bool(eng.fp16_fallback)      # fp16 static stage overflowed on the first batch -> bf16 (pipeline.py)
+    eng.close()                                          # the contexts' packed weights are raw hipMalloc: release them now
     del eng, frames
     torch.cuda.empty_cache()
     return res
@@ -301,6 +398,7 @@ def cpu_baseline(precision, dev, static_precision=None):
     eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=T, precision=precision, device=dev,
                          static_precision=static_precision)
     got = eng(torch.from_numpy(clip[None]).to(dev)).float().cpu().numpy()[0]
+    eng.close()
     del eng
     fix = synth.fixations_from_map(ref, 200, H // 2, W // 2)
     rng = lambda: np.random.RandomState(0)
@@ -373,7 +471,10 @@ def main():
                     help='return_all_steps: one map per ConvLSTM step, [clips, T, 2w, 4w] gathered instead of [clips, 2w, 4w]')
     ap.add_argument('--f32-input', action='store_true', help='frames resident as f32 [H, W, 3] in [0, 1] instead of u8 (SURVEY 8(d))')
     ap.add_argument('--static-only', action='store_true',
-                    help='BASELINE config C2: the static path only (equi -> cube -> ResNet-50 -> CAM); no roofline object')
+                    help='BASELINE config C2: the static path only (equi -> cube -> ResNet-50 -> CAM); roofline = stage flops / time')
+    ap.add_argument('--stub-engine', action='store_true',
+                    help='no GPU: run main() itself (launcher contract, sharding, all-gather, timing, JSON line) on CPU tensors '
+                         'over gloo with a stand-in engine; the numbers mean nothing (tests/test_distributed_cpu.py)')
     ap.add_argument('--cpu-anchor', action='store_true',
                     help='no GPU: time the oracle on the pieces BASELINE.md section 2 timed with the reference itself '
                          '(CAM of one cube, one ConvLSTM step) - the sanity anchor of the cpu_baseline leg')
@@ -382,13 +483,16 @@ def main():
         print(json.dumps(cpu_anchor()))
         return
 
-    rank, world, local = cpdist.init_from_env()
+    rank, world, local = cpdist.init_from_env(backend='gloo' if args.stub_engine else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if args.stub_engine:
+        dev = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     H, W = (int(v) for v in args.equi.split('x'))
     B, T = args.clips, args.frames
     src_hw = tuple(int(v) for v in args.source.split('x')) if args.source else None
@@ -396,7 +500,7 @@ def main():
     head = run_workload(dev, rank, world, H, W, args.cube, B, T, args.precision, args.steps, args.warmup,
                         graph=args.graph, static_only=args.static_only, frame_chunk=args.frame_chunk or None,
                         source_hw=src_hw, want_roofline=(rank == 0), static_precision=args.static_precision or None,
-                        all_steps=args.all_steps, f32_input=args.f32_input)
+                        all_steps=args.all_steps, f32_input=args.f32_input, stub=args.stub_engine, want_split=(rank == 0))
 
     if rank == 0:
         line = {
@@ -425,12 +529,19 @@ def main():
             'ms_per_step_per_rank': head.get('ms_per_step_per_rank'),
             'allgather_ms': head.get('allgather_ms'), 'allgather_bytes_per_rank': head.get('allgather_bytes_per_rank'),
             'map_shape': head.get('map_shape'),
+            # attribution of one box's number (measured after the timed region): where a step's time goes, and the shader
+            # clock this chip holds under a dense bf16 MFMA load (boxes differ: MI355X_MICROARCH.md, DVFS give-back)
+            'stage_ms': head.get('stage_ms'),
+            'held_clock_ghz': None if args.stub_engine else ops.held_clock_ghz(dev),
         }
-        if world == 1 and not args.no_secondary:
+        if args.stub_engine:
+            line['stub_engine'] = True
+            line['data'] = 'stub'
+        if world == 1 and not args.no_secondary and not args.stub_engine:
             sec = []
 
             def add(name, H2, W2, cd2, B2, T2, prec, steps, warmup, **kw):
-                r = run_workload(dev, 0, 1, H2, W2, cd2, B2, T2, prec, steps, warmup, want_roofline=not kw.get('static_only'), **kw)
+                r = run_workload(dev, 0, 1, H2, W2, cd2, B2, T2, prec, steps, warmup, want_roofline=True, **kw)
                 sec.append({'name': name, 'workload': workload_name(kw.get('static_only', False), B2, T2, H2, W2, cd2, r['w'],
                                                                     None, kw.get('all_steps', False), kw.get('f32_input', False)),
                             'dtype': DTYPE[prec], 'static_stage_dtype': r['static_dtype'], 'graph_replay': bool(kw.get('graph')), 'value': r['value'],
@@ -443,6 +554,8 @@ def main():
             add('C3 literal: one 16-frame clip, bf16, eager launches', 1024, 2048, 224, 1, 16, 'bf16', 10, 3)
             add('C3 literal: one 16-frame clip, bf16, hipGraph replay', 1024, 2048, 224, 1, 16, 'bf16', 10, 3, graph=True)
             add('C2: one frame (6 faces), fp32, static path only', 1024, 2048, 224, 1, 1, 'fp32', 20, 5, static_only=True)
+            add('C2: one frame (6 faces), fp32, static path only, hipGraph replay', 1024, 2048, 224, 1, 1, 'fp32', 20, 5,
+                static_only=True, graph=True)
             add('C5 per-GPU shard: one 16-frame 2048x4096 clip, 6x512^2 faces, fp16', 2048, 4096, 512, 1, 16, 'fp16', 3, 1)
             add('C4 per-GPU shard, frames resident as f32 [0,1] instead of u8 (SURVEY 8(d) fp32-input variant)',
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
@@ -450,7 +563,7 @@ def main():
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, all_steps=True)
             sec.append(level1_bench(dev))
             line['secondary'] = sec
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.stub_engine:
             line['cpu_baseline'] = cpu_baseline(args.precision, dev, args.static_precision or None)
         print(json.dumps(line))
     cpdist.barrier()

@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 303
+ABI_VERSION = 304
 
 # every exported symbol of include/cp360.h (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -48,6 +48,7 @@ SYMBOLS = [
     'cp360_fold_bn', 'cp360_create', 'cp360_destroy', 'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward',
     'cp360_clstm_load', 'cp360_clstm_workspace_bytes', 'cp360_clstm_step',
     'cp360_conv_finish_add', 'cp360_window_normalize_frames', 'cp360_clstm_window_workspace_bytes', 'cp360_clstm_window',
+    'cp360_clock_probe', 'cp360_conv_prefer_clip',
 ]
 
 
@@ -173,6 +174,8 @@ def lib():
     L.cp360_clstm_window_workspace_bytes.restype = sz
     L.cp360_clstm_window_workspace_bytes.argtypes = [vp, i, i, i]
     L.cp360_clstm_window.argtypes = [vp, vp, sz, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.cp360_clock_probe.argtypes = [vp, i, i, vp]
+    L.cp360_conv_prefer_clip.argtypes = [pd]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):

@@ -37,148 +37,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in VGPRs (HIP's uint4 struct
-                                                                   // kept one staging set in scratch memory)
-
-struct ConvK {
-    const unsigned char* in;
-    const unsigned char* w;
-    unsigned char* out;
-    const float* bias;
-    const unsigned char* res;
-    float* partial;
-    int n_img, h_in, w_in, c_in, pix_stride, kh, kw, sy, sx, h_out, w_out, c_out;
-    int pad_mode, pad, ld_out, out_coff, ld_res, relu, splits;
-    int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
-    int nt, mt, m_fast;
-    int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
-    int reverse;                          // 1: work items in descending order (cp360_set_launch_order)
-    int epi_direct;                       // 1: direct 16-byte epilogue, 0: LDS-staged epilogue
-    int slab_rows;                        // 1: split-K slabs in packed-row column order (slab_col)
-    // second source (cp360_conv_desc.c_in2 > 0): one extra 1x1 "tap" (index kh*kw, packed behind the others)
-    // gathered from in2 [n_img, h_in2, w_in2, pix_stride2] at (oy * sy2, ox * sx2) - the Bottleneck's downsample
-    // branch accumulated into the conv3 tile (ring kernels only)
-    const unsigned char* in2;
-    int c_in2, c_pad2, pix_stride2, h_in2, w_in2, sy2, sx2, ntap;
-};
-
-template <typename T> struct Elem;
-template <> struct Elem<float> { static constexpr int EPC = 4; };      // elements per 16-byte chunk
-template <> struct Elem<bf16_raw> { static constexpr int EPC = 8; };
-template <> struct Elem<f16_raw> { static constexpr int EPC = 8; };
-
-// 16 zero bytes in device memory: invalid tile rows (m >= M) and the K tail (c >= c_in)
-// load from here, so the select happens on the ADDRESS before the load and nothing has
-// to wait for the loaded data until the ds_write that consumes it.
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
-
-// Channel order inside a 32-row group of the packed weights.  MFMA row block i gives a lane the
-// four consecutive rows 4*(lane>>4) .. +3; the pack kernel permutes the rows so that blocks 2p
-// and 2p+1 TOGETHER give it EIGHT consecutive channels:  packed row 32q + 16*b + 4*g + e  holds
-// channel 32q + 8*g + 4*b + e.  A lane then owns a 16-byte (bf16) / 32-byte (f32) piece of a pixel
-// and the four lane groups of a pixel 64 / 128 contiguous bytes: outputs, residuals and split-K
-// slabs are moved with 16-byte accesses straight from / to global memory.
-__device__ __forceinline__ int acc_chan(int i, int lane) { return (i >> 1) * 32 + (lane >> 4) * 8 + (i & 1) * 4; }
-// Split-K slabs (cp360_conv_desc.slab_rows) keep the PACKED row order inside each 32-channel group, so the
-// four lane groups of a pixel store 64 contiguous bytes per MFMA block (in true channel order a store
-// instruction would write 16-byte pieces 32 bytes apart: +37 % HBM write traffic measured).  Column of the
-// 4-channel group that starts at channel n (n % 4 == 0):
-__host__ __device__ __forceinline__ int slab_col(int n) { return (n & ~31) + ((n >> 3) & 3) * 4 + ((n >> 2) & 1) * 16; }
-
-__device__ __forceinline__ int lds_swz(int row, int chunk) {
-    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-template <typename T>
-__device__ __forceinline__ void mma_chunk(f32x4& acc, const u32x4& a, const u32x4& b);
-
-template <>
-__device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma_chunk<bf16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc,
-                                                  0, 0, 0);
-}
-
-template <>
-__device__ __forceinline__ void mma_chunk<f16_raw>(f32x4& acc, const u32x4& a, const u32x4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0,
-                                                 0, 0);
-}
-
-template <typename T> __device__ __forceinline__ float load_as_f32(const T* p);
-template <> __device__ __forceinline__ float load_as_f32<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float load_as_f32<bf16_raw>(const bf16_raw* p) { return bf16_to_f32(*p); }
-
-// store 4 consecutive channels
-__device__ __forceinline__ void store4(float* p, const float v[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void store4(bf16_raw* p, const float v[4]) {
-    uint2 o;
-    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = o;
-}
-__device__ __forceinline__ void store4(f16_raw* p, const float v[4]) {
-    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-    const f16x4 o = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3]};
-    *reinterpret_cast<f16x4*>(p) = o;
-}
-__device__ __forceinline__ void load4(const f16_raw* p, float v[4]) {
-    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-    const f16x4 t = *reinterpret_cast<const f16x4*>(p);
-    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
-}
-__device__ __forceinline__ void load4(const float* p, float v[4]) {
-    float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-__device__ __forceinline__ void load4(const bf16_raw* p, float v[4]) {
-    uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-}
-
-// ------------------------------------------------------------------ direct epilogue (16-byte pieces)
-// With the acc_chan row order a lane owns 8 consecutive channels of a pixel per block pair: bias,
-// residual, ReLU, ONE rounding and the store happen on 16-byte pieces straight against global memory
-// (a pixel's four lane groups cover 64 bytes (16-bit types) / 128 bytes (f32) contiguously) - no LDS
-// round trip, no barriers, and the residual loads of JB pixel blocks are in flight together.
-__device__ __forceinline__ u32x4 pack8(const float v[8], bf16_raw) {
-    u32x4 o;
-    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-    return o;
-}
-__device__ __forceinline__ u32x4 pack8(const float v[8], f16_raw) {
-    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
-    const f16x8v h = {(f16_raw)v[0], (f16_raw)v[1], (f16_raw)v[2], (f16_raw)v[3],
-                      (f16_raw)v[4], (f16_raw)v[5], (f16_raw)v[6], (f16_raw)v[7]};
-    return __builtin_bit_cast(u32x4, h);
-}
-__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], bf16_raw) {
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
-    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
-}
-__device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
-    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8v;
-    const f16x8v h = __builtin_bit_cast(f16x8v, r);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
-}
+#include "conv_common.h"
 
 // (Requesting the residual pieces BEFORE the K loop of the short-K kernel was tried: the 16-32 extra registers spill
 // under its 128-VGPR budget and the launch got 40 % slower - layer3 conv3 110 -> 155 us.)
@@ -1664,8 +1523,9 @@ static int check_desc(const cp360_conv_desc* d) {
         return CP360_ERR_BAD_SHAPE;
     const int epc = 16 / elem_bytes(d->dtype);
     if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 256 &&
-        d->tile_px != 304)
+        d->tile_px != 304 && d->tile_px != 6464)
         return CP360_ERR_BAD_SHAPE;
+    if (d->tile_px == 6464 && (d->clip_resident || d->c_out % 8 != 0)) return CP360_ERR_UNSUPPORTED;   // conv_small.hip
     if (d->tile_px == 129 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;   // 16-bit types only (128-VGPR budget)
     if (d->slab_rows != 0 && d->slab_rows != 1) return CP360_ERR_BAD_SHAPE;
     if (d->slab_rows && d->c_out % 32 != 0) return CP360_ERR_ALIGN;
@@ -1745,7 +1605,57 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
     return best;
 }
 
+// conv_small.hip: 64 x 64 tiles, 4 waves, up to four workgroups per CU.  f32 steps are MFMA-bound (1024 cycles per SIMD
+// for a 128-byte K step; workgroups that share a CU share its matrix pipes), so a launch costs about
+// (workgroups per CU) x steps x 0.5 us + a fixed 3 us per wave of 1024 workgroups.
+static bool small_eligible(const cp360_conv_desc* d) {
+    static const int small = []() {
+        const char* e = getenv("CP360_SMALL");               // A/B switch: 0 = never, 1 = f32 only (default), 2 = every dtype
+        return e ? atoi(e) : 1;
+    }();
+    if (!small || d->clip_resident || d->c_out % 8 != 0) return false;
+    if (d->dtype != CP360_F32) {
+        if (small < 2) return false;
+        if (d->ld_out % 8 != 0 || d->out_coff % 8 != 0 || d->ld_res % 8 != 0) return false;
+    }
+    return true;
+}
+
+static ConvPlan plan_small(const cp360_conv_desc* d) {
+    const long long M = (long long)d->n_img * d->h_out * d->w_out;
+    const long long tiles = ((d->c_out + 63) / 64) * ((M + 63) / 64);
+    const int bk = bk_of(d->dtype);
+    const int nsteps = d->kh * d->kw * (round_up(d->c_in, bk) / bk) + c_pad2_of(d) / bk;
+    const double t_step = d->dtype == CP360_F32 ? 0.5 : 0.2;
+    ConvPlan best{64, 64, 1024, 1, 0.0};
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && nsteps / s < 4) break;
+        const long long W = tiles * s;
+        const int steps = (nsteps + s - 1) / s;
+        const long long per_cu = d->dtype == CP360_F32 ? (W + 255) / 256 : (W + 1023) / 1024;
+        double cost = (double)((W + 1023) / 1024) * 3.0 + (double)per_cu * steps * t_step;
+        if (s > 1) cost += 4.0 + (double)s * (double)M * d->c_out * 8.0 / 4.0e6;
+        if (s == 1 || cost < best.cost) {
+            best.splits = s;
+            best.cost = cost;
+        }
+    }
+    return best;
+}
+
+static ConvPlan plan_big(const cp360_conv_desc* d);
+
 static ConvPlan plan_of(const cp360_conv_desc* d) {
+    ConvPlan best = plan_big(d);
+    if (d->tile_px == 6464) return plan_small(d);
+    if (d->tile_px == 0 && small_eligible(d)) {
+        const ConvPlan sm = plan_small(d);
+        if (sm.cost < best.cost) best = sm;
+    }
+    return best;
+}
+
+static ConvPlan plan_big(const cp360_conv_desc* d) {
     if (d->clip_resident) {
         // one 256-channel x clip tile per workgroup, 64-byte sub-steps; about 0.9 us per sub-step
         const int wgs = ((d->c_out + 255) / 256) * (d->h_in == 16 ? d->n_img : d->n_img / 6);   // tile = face at 16x16
@@ -1806,6 +1716,7 @@ static void tile_of(const cp360_conv_desc* d, int* bn, int* bm, int* slots) {
     *bn = pl.bn;
     *bm = pl.bm;
     *slots = pl.slots;
+    if (pl.bm == 64) return;                         // conv_small.hip (chosen by the model or forced by tile_px 6464)
     if (d->c_out >= 256 && d->tile_px == 64) {       // forced: the 4-wave 128x128 kernel
         *bn = 128;
         *bm = 128;
@@ -1822,6 +1733,24 @@ extern "C" int cp360_conv_suggest_splits(const cp360_conv_desc* d) {
     t.splits = 1;
     if (check_desc(&t)) return 1;
     return plan_of(&t).splits;
+}
+
+// For a caller that holds BOTH weight layouts of a CubePad(1) + 3x3 convolution on small faces (layer4's conv2): should this
+// launch take the clip-resident kernel (1) or the tap-major path (0)?  The clip-resident tile is 256 channels x a whole cube:
+// with few cubes and few channels (one frame, 512 channels: 2 tiles) it cannot fill the chip even with split-K, and the
+// 64 x 64 tiles of conv_small.hip win.  Only that comparison is made: where the small-tile kernel is not eligible (16-bit
+// types by default) the answer is 1, as before round 4.
+extern "C" int cp360_conv_prefer_clip(const cp360_conv_desc* d) {
+    if (!d) return 0;
+    cp360_conv_desc c = *d;
+    c.splits = 1;
+    c.tile_px = 0;
+    c.clip_resident = 1;
+    if (check_desc(&c)) return 0;
+    cp360_conv_desc t = c;
+    t.clip_resident = 0;
+    if (check_desc(&t) || !small_eligible(&t)) return 1;
+    return plan_big(&c).cost <= plan_small(&t).cost ? 1 : 0;
 }
 
 static int pack_weights_impl(const cp360_conv_desc* d, const float* w_oihw, const float* scale, const float* w2,
@@ -1952,7 +1881,13 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     }
     const bool narrow = d->c_out <= 64;
     int bn_ = 0, bm_ = 0, slots_ = 0;
-    if (d->c_out >= 256) tile_of(d, &bn_, &bm_, &slots_);
+    tile_of(d, &bn_, &bm_, &slots_);
+    if (bm_ == 64) {                                           // small-M launches: 64 x 64 tiles (conv_small.hip)
+        cp360_launch_conv_small(k, d->dtype, st);
+        CP360_CHECK_HIP();
+        return CP360_OK;
+    }
+    if (d->c_out < 256) bn_ = bm_ = slots_ = 0;
     const bool wide = d->c_out >= 256 && bn_ == 256;           // else: the 4-wave 128x128 kernel, two workgroups per CU
     if (d->c_in2 > 0) {                                        // second source: ring kernels only
         if (!wide) return CP360_ERR_UNSUPPORTED;

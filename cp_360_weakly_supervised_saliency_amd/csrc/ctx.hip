@@ -132,6 +132,19 @@ bool clip_geometry(const CConv& c, int n_img, int h, int w) {
     return c.clip_ok && h == w && (6 * h * w <= 304 || h == 16) && n_img % 6 == 0;
 }
 
+void fill_desc(const CConv& c, int dtype, int n_img, int h_in, int w_in, int splits, int ld_out, int out_coff,
+               int ld_res, int clip_resident, int slab_rows, int h2, int w2, int ps2, cp360_conv_desc* d);
+
+// clip-resident kernel or tap-major path?  With one packing there is no choice; with both (layer4's conv2) the library's cost
+// model decides (cp360_conv_prefer_clip: one frame in f32 runs better on the 64 x 64 tiles of conv_small.hip)
+bool use_clip(const CConv& c, int dtype, int n_img, int h, int w) {
+    if (!clip_geometry(c, n_img, h, w) || !c.packed_clip) return false;
+    if (!c.packed) return true;
+    cp360_conv_desc d;
+    fill_desc(c, dtype, n_img, h, w, 1, 0, 0, 0, 1, 0, 0, 0, 0, &d);
+    return cp360_conv_prefer_clip(&d) != 0;
+}
+
 // The launch (or, with `dry`, only the split-K workspace it needs): ops.Conv.__call__.
 //   raw: leave the f32 sums in `partial` ([splits, M, c_out]; *splits_out tells how many) for the caller's epilogue.
 struct Run {
@@ -148,7 +161,7 @@ struct Run {
              int ld_out, int out_coff, const void* x2, int h2, int w2, int ps2, bool raw, bool raw_slab_rows,
              float* raw_dst, int force_splits, int* splits_out) {
         cp360_conv_desc d;
-        const int cr = clip_geometry(c, n_img, h, w) ? 1 : 0;
+        const int cr = use_clip(c, dtype, n_img, h, w) ? 1 : 0;
         fill_desc(c, dtype, n_img, h, w, 1, ld_out, out_coff, ld_res, cr, 0, h2, w2, ps2, &d);
         const int splits = force_splits > 0 ? force_splits : cp360_conv_suggest_splits(&d);
         const bool extra = finish_extra != nullptr && !raw;          // the sums go through cp360_conv_finish_add even at splits = 1
@@ -158,7 +171,10 @@ struct Run {
         if (splits_out) *splits_out = splits;
         const size_t M = (size_t)n_img * d.h_out * d.w_out;
         const bool to_partial = raw || splits > 1 || extra;
-        if (to_partial && !raw_dst) {
+        // raw sums with a caller-owned destination AND split-K (the CAM scores at one frame): slabs in the workspace,
+        // reduced into raw_dst by an f32 finish
+        const bool raw_reduce = raw && raw_dst && splits > 1;
+        if (to_partial && (!raw_dst || raw_reduce)) {
             const size_t need = (size_t)splits * M * c.c_out * sizeof(float);
             if (need > partial_need) partial_need = need;
             if (!dry && need > partial_cap) return CP360_ERR_BAD_SHAPE;
@@ -167,9 +183,16 @@ struct Run {
         const void* pk = cr ? c.packed_clip : c.packed;
         if (!pk) return CP360_ERR_UNSUPPORTED;
         if (to_partial) {
-            float* dst = raw_dst ? raw_dst : partial;
+            float* dst = raw_dst && !raw_reduce ? raw_dst : partial;
             int rc = cp360_conv_forward2(&d, in, x2, pk, nullptr, nullptr, nullptr, dst, st);
-            if (rc || raw) return rc;
+            if (rc) return rc;
+            if (raw_reduce) {
+                cp360_conv_desc df = d;
+                df.dtype = CP360_F32;
+                df.relu = 0;
+                return cp360_conv_finish_add(&df, dst, nullptr, nullptr, nullptr, raw_dst, st);
+            }
+            if (raw) return rc;
             const float* ex = finish_extra;
             finish_extra = nullptr;
             return cp360_conv_finish_add(&d, dst, ex, c.bias, residual, out, st);
@@ -568,7 +591,7 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
     }
     if (!dry) cp360_set_launch_order(old_order);
     // ---- CAM: raw f32 scores [n_img, face, face, num_classes] straight into the caller's buffer (no bias / activation)
-    CK(run.conv(R.cam, buf[cur], n_img, face, face, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, 0, true, false, dry ? (float*)1 : cam_out, 1,
+    CK(run.conv(R.cam, buf[cur], n_img, face, face, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, 0, true, false, dry ? (float*)1 : cam_out, 0,
                 nullptr));
     if (!dry && feat_out &&
         hipMemcpyAsync(feat_out, buf[cur], (size_t)n_img * face * face * 2048 * es, hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -734,9 +757,11 @@ struct WindowWs {
 };
 
 bool window_batches_x(const CClstm& Cl, int n_clips) {
-    static const int env = []() { const char* e = getenv("CP360_XBATCH"); return e ? atoi(e) : -1; }();
-    if (!Cl.split_ok) return false;
-    return env < 0 ? n_clips <= 2 : env != 0;
+    // Opt-in (CP360_XBATCH=1; measured performance-neutral): it changes Conv1's accumulation order, so
+    // the default window issues exactly the launches of T cp360_clstm_step calls and gives the same bits
+    static const int env = []() { const char* e = getenv("CP360_XBATCH"); return e ? atoi(e) : 0; }();
+    (void)n_clips;
+    return Cl.split_ok && env != 0;
 }
 
 int window_plan(cp360_ctx* ctx, int n_clips, int T, int face, WindowWs* w) {

@@ -1101,8 +1101,8 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
             const size_t lds6 = 768 + (size_t)6 * pstride;
             if (!no_strip && !no_lds6 && P >= 1 && nlines <= 16 && g.n >= E && CH * nn >= E && lds6 <= 160 * 1024 &&
                 CH * HW < (1 << 22) && items >= lds6_min && items < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
-                (reinterpret_cast<size_t>(x) % ES) == 0) {
-                if (int rc = ensure_big_lds<&cubepad_nchw_lds6_kernel<ES>>()) return rc;
+                (reinterpret_cast<size_t>(x) % ES) == 0 &&
+                ensure_big_lds<&cubepad_nchw_lds6_kernel<ES>>() == CP360_OK) {    // (refused: on down the chain to the <= 64 KB kernels)
                 static const int force_nt6 = []() { const char* e = getenv("CP360_CUBEPAD_LDS6_NT"); return e ? atoi(e) : 0; }();
                 int per_cu = (int)((size_t)160 * 1024 / lds6);
                 int nt = per_cu >= 4 ? 256 : (per_cu >= 2 ? 512 : 1024);
@@ -1146,8 +1146,8 @@ static int launch_nchw(const void* x, void* y, int n6, int C, const CubePadGeom&
             if (!no_strip && !strip_v1 && !no_channel && P >= 1 && P <= E && g.n * ES >= strip_min && nlines <= 16 &&
                 g.n >= 2 * E + LR && g.n >= 2 * P && lds3 <= 160 * 1024 && (long long)Hp * Wp < (1 << 22) && items >= channel_min &&
                 items < (1ll << 31) && (long long)g.n * g.n < (1ll << 31) && (reinterpret_cast<size_t>(y) % ES) == 0 &&
-                (reinterpret_cast<size_t>(x) % ES) == 0) {
-                if (int rc = ensure_big_lds<&cubepad_nchw_channel_kernel<ES>>()) return rc;
+                (reinterpret_cast<size_t>(x) % ES) == 0 &&
+                ensure_big_lds<&cubepad_nchw_channel_kernel<ES>>() == CP360_OK) {
                 // one wave per face while that gives >= 12 waves per CU, two (768 threads) for few / large items
                 static const int force_nt = []() { const char* e = getenv("CP360_CUBEPAD_CHANNEL_NT"); return e ? atoi(e) : 0; }();
                 int nt = items >= 512 ? 384 : 768;
@@ -1320,9 +1320,10 @@ extern "C" int cp360_cubepad_nhwc(const void* x, void* y, int n6, int C, int Cy,
     uint32_t* yo = (uint32_t*)y;
     static const int no_px = []() { const char* e = getenv("CP360_CUBEPAD_NHWC_NOPX"); return e ? atoi(e) : 0; }();   // A/B switch
     const long long total_px = (long long)n6 * Hp * Wp;
-    if (!no_px && vec < 4 && cw <= 4 && cyw <= 8 && total_px < (1ll << 32)) {      // narrow pixels: a thread per pixel
-        long long pb = (total_px + 255) / 256;
-        if (pb > 256 * 16) pb = 256 * 16;
+    long long pb = (total_px + 255) / 256;
+    if (pb > 256 * 16) pb = 256 * 16;
+    // narrow pixels: a thread per pixel (32-bit pixel index: the grid-stride increment must not wrap either)
+    if (!no_px && vec < 4 && cw <= 4 && cyw <= 8 && total_px < (1ll << 32) - pb * 256) {
 #define CP360_PX(CWV) hipLaunchKernelGGL((cubepad_nhwc_px_kernel<CWV>), dim3((unsigned)pb), dim3(256), 0, st, xi, yo, (unsigned)total_px, cyw, g)
         if (cw == 1) CP360_PX(1); else if (cw == 2) CP360_PX(2); else if (cw == 3) CP360_PX(3); else CP360_PX(4);
 #undef CP360_PX

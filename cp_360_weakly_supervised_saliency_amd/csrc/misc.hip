@@ -207,6 +207,15 @@ extern "C" int cp360_nhwc_to_nchw(const void* x, void* y, int N, int C, int H, i
 // test_temporal.py:66-67: max / min over every value of the window's T cube_feat arrays.
 // Pass 1: 256 workgroups per clip, each reduces a slice to one (min, max) pair in
 // `scratch`; pass 2 (one workgroup per clip) folds the 256 pairs.  No float atomics.
+// Non-finite inputs (an fp16 static stage whose activations passed 65504: inf, then inf - inf = NaN) POISON the pair:
+// fminf / fmaxf drop a NaN, so pass 1 also tests every value's exponent field and a window that holds an inf or a NaN
+// gets min = max = NaN - as numpy's max / min over such a window would give NaN (test_temporal.py:66-67) - which the
+// normalisation spreads over the whole map and which pipeline.py reads back as its overflow flag (8 bytes per window).
+__device__ __forceinline__ unsigned nonfinite_bits(const float4& v) {
+    const unsigned e = 0x7f800000u;
+    return (unsigned)((__float_as_uint(v.x) & e) == e) | (unsigned)((__float_as_uint(v.y) & e) == e) |
+           (unsigned)((__float_as_uint(v.z) & e) == e) | (unsigned)((__float_as_uint(v.w) & e) == e);
+}
 __device__ __forceinline__ void wave_minmax(float& mn, float& mx) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -221,12 +230,15 @@ __global__ __launch_bounds__(256) void minmax_pass1(const float* __restrict__ x,
     const float4* xv = reinterpret_cast<const float4*>(x + (size_t)b * clip_stride);
     const size_t nv = per_clip / 4;
     float mn = INFINITY, mx = -INFINITY;
+    unsigned bad = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
         const float4 v = xv[i];
         mn = fminf(fminf(mn, v.x), fminf(fminf(v.y, v.z), v.w));
         mx = fmaxf(fmaxf(mx, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+        bad |= nonfinite_bits(v);
     }
     wave_minmax(mn, mx);
+    const int any_bad = __syncthreads_or((int)bad);
     __shared__ float s[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
@@ -239,6 +251,7 @@ __global__ __launch_bounds__(256) void minmax_pass1(const float* __restrict__ x,
             mn = fminf(mn, s[w * 2]);
             mx = fmaxf(mx, s[w * 2 + 1]);
         }
+        if (any_bad) mn = mx = __uint_as_float(0x7fc00000u);
         scratch[((size_t)b * gridDim.x + blockIdx.x) * 2] = mn;
         scratch[((size_t)b * gridDim.x + blockIdx.x) * 2 + 1] = mx;
     }
@@ -248,11 +261,15 @@ __global__ __launch_bounds__(256) void minmax_pass2(const float* __restrict__ sc
                                                     int nblk) {
     const int b = blockIdx.x;
     float mn = INFINITY, mx = -INFINITY;
+    int bad = 0;
     for (int i = threadIdx.x; i < nblk; i += 256) {
-        mn = fminf(mn, scratch[((size_t)b * nblk + i) * 2]);
-        mx = fmaxf(mx, scratch[((size_t)b * nblk + i) * 2 + 1]);
+        const float a = scratch[((size_t)b * nblk + i) * 2], c = scratch[((size_t)b * nblk + i) * 2 + 1];
+        bad |= (a != a) || (c != c);                          // a slice that pass 1 poisoned
+        mn = fminf(mn, a);
+        mx = fmaxf(mx, c);
     }
     wave_minmax(mn, mx);
+    const int any_bad = __syncthreads_or(bad);
     __shared__ float s[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) {
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(256) void minmax_pass2(const float* __restrict__ sc
             mn = fminf(mn, s[w * 2]);
             mx = fmaxf(mx, s[w * 2 + 1]);
         }
+        if (any_bad) mn = mx = __uint_as_float(0x7fc00000u);
         minmax[b * 2] = mn;
         minmax[b * 2 + 1] = mx;
     }
@@ -360,6 +378,67 @@ extern "C" int cp360_window_normalize_frames(const float* x, const float* minmax
                            clip_stride, 0, P, C, ts);
     else
         return CP360_ERR_BAD_DTYPE;
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+// ---------------------------------------------------------------- diagnostic: the shader clock held under load
+// MI355X lowers its clock under a dense-MFMA load and boxes differ (MI355X_MICROARCH.md, "DVFS give-back" items 5-6), which
+// moves the bench line by more than a round's kernel work.  This kernel is a bare bf16 MFMA loop on pseudo-random operands
+// (one wave per SIMD on every CU, 16 independent accumulators) stamped once around the loop with s_memtime (shader cycles)
+// and s_memrealtime (100 MHz): held clock = d(memtime) / d(memrealtime) x 0.1 GHz.  The stamps go to a buffer of their own
+// that nothing else reads; no output of the library is computed from them.  bench.py reports the median over workgroups as
+// `held_clock_ghz`, so two driver runs on different boxes can be told apart.
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ stamps, int iters) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const unsigned tid = threadIdx.x + blockIdx.x * 256u;
+    u32x4_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned h = (tid * 2654435761u) ^ ((unsigned)(i * 4 + e + 1) * 0x9E3779B9u);
+            h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+            // two bf16 values in [1, 2) with random signs and mantissas: finite sums, random toggling of the multipliers
+            a[i][e] = 0x3F803F80u | (h & 0x807F807Fu);
+            b[i][e] = 0x3F803F80u | ((h * 0xC2B2AE35u) & 0x807F807Fu);
+        }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[j]),
+                                                                    acc[i][j], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    const int wave = tid >> 6;
+    if ((threadIdx.x & 63) == 0 || s == 1.2345e-30f) {          // (the second term keeps the loop alive; it never holds)
+        stamps[wave * 2] = t1 - t0;
+        stamps[wave * 2 + 1] = r1 - r0;
+    }
+}
+
+extern "C" int cp360_clock_probe(unsigned long long* stamps, int n_workgroups, int iters, void* stream) {
+    if (!stamps) return CP360_ERR_NULL;
+    if (n_workgroups <= 0 || iters <= 0) return CP360_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, (hipStream_t)stream, stamps, iters);
     CP360_CHECK_HIP();
     return CP360_OK;
 }

@@ -211,6 +211,7 @@ class Conv:
             clip_resident = (not stem and self.pad == 1 and self.stride == 1 and self.kh == 3 and self.kw == 3
                              and self.c_out >= 256)
         self.clip_resident_ok = bool(clip_resident)
+        self.clip_only = False                  # True: never ask cp360_conv_prefer_clip (only the channel-major packing exists)
         # second source (cp360_conv_desc.c_in2): (weight2 [c_out, c_in2, 1, 1], scale2, bias2, stride2) - a 1x1
         # convolution of a SECOND tensor accumulated into the same tile (the Bottleneck's downsample branch
         # inside conv3); its bias is folded into this conv's bias
@@ -344,6 +345,33 @@ class Conv:
         bk = 32 if self.dtype == torch.float32 else 64
         return self.kh * self.kw * ((self.c_in + bk - 1) // bk)
 
+    def raw_sum_f32(self, x, out=None):
+        """The convolution's raw f32 sums [n_img, h_out, w_out, c_out] (no bias / activation, true channel order) - how the
+        CAM scores leave (class_activation_model.py:77-83).  The library's planner may split K (one frame = 6 faces gives a
+        CAM GEMM of M = 294 rows: 80 small tiles for 256 CUs); the slabs are then reduced by cp360_conv_finish with an f32
+        descriptor.  ``out``: f32 buffer of >= M * c_out elements (flat), else a fresh tensor."""
+        n_img, h_in, w_in, _ = x.shape
+        h_out, w_out = self.out_hw(h_in, w_in)
+        M = n_img * h_out * w_out
+        key = (n_img, h_in, w_in, 0)
+        splits = self._splits_cache.get(key)
+        if splits is None:
+            splits = lib().cp360_conv_suggest_splits(C.byref(self._desc(n_img, h_in, w_in, 1)))
+            self._splits_cache[key] = splits
+        if splits == 1:
+            part, _ = self(x, raw_f32=True, splits=1, partial_buf=out, clip_resident=False)
+            return part[: M * self.c_out].view(n_img, h_out, w_out, self.c_out)
+        part, _ = self(x, raw_f32=True, splits=splits, clip_resident=False)
+        if out is None:
+            out = torch.empty(M * self.c_out, dtype=torch.float32, device=x.device)
+        else:
+            require_gpu(out)
+            _check_buf('out', out, torch.float32, numel=M * self.c_out)
+        d = self._desc(n_img, h_in, w_in, splits, relu=False)
+        d.dtype = dtype_code(torch.float32)                     # the finish writes f32 whatever the convolution's type
+        check(lib().cp360_conv_finish(C.byref(d), ptr(part), None, None, ptr(out), stream()))
+        return out.view(-1)[: M * self.c_out].view(n_img, h_out, w_out, self.c_out)
+
     def __call__(self, x, residual=None, out=None, out_coff=0, raw_f32=False, splits=None, partial_buf=None,
                  tile_px=0, clip_resident=None, slab_rows=False, x2=None):
         """x [n_img, h, w, c] NHWC (for the stem: the materialised CubePad(3) output
@@ -390,6 +418,15 @@ class Conv:
         cr = int(cr and h_in == w_in and (6 * h_in * w_in <= 304 or h_in == 16) and n_img % 6 == 0 and tile_px == 0)
         if clip_resident and not cr:
             raise ValueError("clip_resident needs CubePad(1)+3x3 stride 1 on faces of at most 7x7, or 16x16")
+        if cr and clip_resident is None and not self.clip_only:
+            # both layouts can be packed: few cubes x few channels (layer4's conv2 of one frame) run better on the small
+            # tap-major tiles (cp360_conv_prefer_clip; same rule in csrc/ctx.hip)
+            key = ('clip', n_img, h_in, w_in)
+            pref = self._splits_cache.get(key)
+            if pref is None:
+                pref = L.cp360_conv_prefer_clip(C.byref(self._desc(n_img, h_in, w_in, 1, clip_resident=1)))
+                self._splits_cache[key] = pref
+            cr = int(bool(pref))
         if splits is None:
             key = (n_img, h_in, w_in, cr)
             splits = self._splits_cache.get(key)
@@ -723,3 +760,24 @@ def window_normalize(x, minmax, y, y_coff, y2, B, T, t, P, Cc, clip_stride=0):
         raise ValueError("y must be contiguous [.., ld] with B*P pixels and y_coff + C <= ld")
     check(lib().cp360_window_normalize(ptr(x), ptr(minmax), ptr(y), dtype_code(y.dtype), y.shape[-1], y_coff,
                                        ptr(y2), B, T, t, P, Cc, clip_stride, stream()))
+
+
+def held_clock_ghz(device='cuda', ms=6.0, launches=3):
+    """Diagnostic (never on the hot path): the shader clock the chip holds under a dense bf16 MFMA load on random operands -
+    cp360_clock_probe (csrc/misc.hip), one wave per SIMD on every CU, median over the waves of the last of ``launches``
+    back-to-back launches of about ``ms`` milliseconds each.  MI355X boxes differ in the clock they hold (DVFS), which moves
+    a bench line by more than a round of kernel work: bench.py prints this next to its numbers."""
+    dev = torch.device(device)
+    n_wg = torch.cuda.get_device_properties(dev).multi_processor_count
+    stamps = torch.zeros((n_wg * 4, 2), dtype=torch.int64, device=dev)
+    iters = max(1, int(ms * 1e-3 * 1.8e9 / (16 * 16)))            # 16 MFMAs of 16 cycles per iteration at about 1.8 GHz
+    with torch.cuda.device(dev):
+        for _ in range(launches):
+            check(lib().cp360_clock_probe(ptr(stamps), n_wg, iters, stream()))
+        torch.cuda.synchronize()
+    s = stamps.cpu().double()
+    ok = s[:, 1] > 0
+    if not bool(ok.any()):
+        return None
+    ghz = 0.1 * s[ok, 0] / s[ok, 1]
+    return round(float(ghz.median()), 4)

@@ -41,12 +41,16 @@ class SaliencyEngine:
         # runs in; fp16 ResNet + bf16 ConvLSTM -> 5.2e-4, dCC 2.2e-4.
         self.precision = precision
         self.static_precision = static_precision or ('fp16' if precision == 'bf16' else precision)
-        # fp16 has a 5-bit exponent (max 65504) where bf16 has f32's range.  When the fp16 static stage was chosen BY
-        # DEFAULT for a bf16 engine, the first batch is checked once: non-finite CAM scores (a checkpoint whose
-        # folded-BN scales / activations exceed fp16's range) switch the static stage to bf16 - never silently wrong:
-        # ``static_precision`` / ``fp16_fallback`` say what runs, and bench.py reports them.  An explicit
-        # static_precision='fp16' (or precision='fp16') is honoured as given; ``nonfinite()`` lets a caller check any batch.
-        self._guard_pending = static_precision is None and precision == 'bf16'
+        # fp16 has a 5-bit exponent (max 65504) where bf16 has f32's range (the reference runs fp32,
+        # class_activation_model.py:55-64).  When the fp16 static stage was chosen BY DEFAULT for a bf16 engine, EVERY batch
+        # is checked: the window min / max kernel - which reads every CAM score anyway - poisons a window's (min, max) pair
+        # with NaN when it meets an inf / NaN (csrc/misc.hip), and the engine reads those 8 bytes per clip back after the
+        # batch.  A non-finite pair (a checkpoint or a clip whose activations exceed fp16's range) switches the static stage
+        # to bf16 for good and recomputes THIS batch - never silently wrong: ``static_precision`` / ``fp16_fallback`` say
+        # what runs, and bench.py reports them.  The read-back makes the host wait for the batch (it cannot queue the next
+        # one early: about one launch latency per batch).  An explicit static_precision='fp16' (or precision='fp16') is
+        # honoured as given and not checked; ``nonfinite()`` lets a caller check any batch.
+        self._guard = static_precision is None and precision == 'bf16'
         self.fp16_fallback = False
         self.dtype = _lib.precision_dtype(self.static_precision)
         self.B, self.T = int(clips), int(frames)
@@ -77,6 +81,7 @@ class SaliencyEngine:
         self.runner = ClipRunner(self.cell, self.c2e, self.B, self.T, self.w)
         self.cam = torch.empty((self.B, self.T, 6 * self.w * self.w, input_size), dtype=torch.float32,
                                device=self.device)
+        self._mm_host = None                               # pinned copy of the runner's [B, 2] window min / max
 
     def static_stage(self, frames):
         """frames u8/f32 [F, H, W, 3] on the device -> CAM f32 [F, 6*w*w, 1000] written
@@ -115,16 +120,32 @@ class SaliencyEngine:
             self._graph = g
         return self
 
+    def close(self):
+        """Release the device memory the engine owns outside torch's allocator (the stage contexts' packed weights) and
+        its cached workspaces; the engine re-packs on the next call.  ``del engine`` does the same through the objects'
+        finalisers (the stage objects hold their modules weakly, so there is no cycle to wait for)."""
+        self._graph = None
+        for mod in (self.resnet, self.cell):
+            st = mod.__dict__.get('_stage')
+            if st is not None:
+                st.close()
+
     def nonfinite(self):
-        """True when the last batch's CAM scores hold an inf / NaN (one device reduction + a sync: a check to run on
-        demand, not inside the hot loop).  With an fp16 static stage this is how activations beyond 65504 show."""
-        return not bool(torch.isfinite(self.cam).all())
+        """True when the last batch's CAM scores held an inf / NaN: the window min / max pairs of that batch (poisoned
+        with NaN by the reduction kernel, csrc/misc.hip) read back - 8 bytes per clip and a sync.  With an fp16 static
+        stage this is how activations beyond 65504 show."""
+        if self._mm_host is None:
+            self._mm_host = torch.empty(tuple(self.runner.minmax.shape), dtype=torch.float32).pin_memory()
+        self._mm_host.copy_(self.runner.minmax, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return not bool(torch.isfinite(self._mm_host).all())
 
     def _fallback_to_bf16(self):
         self.resnet.set_precision('bf16')                  # plans are re-packed on the next call (the stamp changed)
         self.static_precision = 'bf16'
         self.dtype = _lib.precision_dtype('bf16')
         self.fp16_fallback = True
+        self._guard = False
 
     def _forward(self, frames):
         B, T = frames.shape[:2]
@@ -132,12 +153,13 @@ class SaliencyEngine:
             raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
         flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
         self.static_stage(flat)
-        if self._guard_pending:                            # first batch only (and never during graph capture)
-            self._guard_pending = False
-            if self.static_precision == 'fp16' and self.nonfinite():
-                self._fallback_to_bf16()
-                self.static_stage(flat)
-        return self.temporal_stage()
+        sal = self.temporal_stage()
+        # every batch (never during graph capture - replays are checked in __call__): see __init__
+        if self._guard and self.static_precision == 'fp16' and not torch.cuda.is_current_stream_capturing() and self.nonfinite():
+            self._fallback_to_bf16()
+            self.static_stage(flat)
+            sal = self.temporal_stage()
+        return sal
 
     def __call__(self, frames):
         """frames [B, T, H, W, 3] (u8 or f32, device) -> saliency f32 [B, 2w, 4w] ([B, T, 2w, 4w] with
@@ -148,6 +170,10 @@ class SaliencyEngine:
                     raise ValueError("graph captured for %s %s frames" % (tuple(self._graph_in.shape), self._graph_in.dtype))
                 self._graph_in.copy_(frames)
                 self._graph.replay()
+                if self._guard and self.static_precision == 'fp16' and self.nonfinite():
+                    self._graph = None                     # the captured launches are the fp16 ones: back to eager, in bf16
+                    self._fallback_to_bf16()
+                    return self._forward(frames)
                 return self._graph_out
             return self._forward(frames)
 

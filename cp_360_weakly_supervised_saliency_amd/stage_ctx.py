@@ -8,6 +8,7 @@ points) - both paths issue the same launches and give the same bits (tests/test_
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -34,13 +35,19 @@ class StageCtx:
         self.h = h
         self._ws = {}
 
-    def __del__(self):
+    def close(self):
+        """Free the context's packed weights (raw hipMalloc: torch's caching allocator cannot reclaim them) and drop the
+        cached workspaces.  Idempotent; also runs when the object is collected."""
         h, self.h = getattr(self, 'h', None), None
+        self._ws = {}
         if h:
             try:
                 lib().cp360_destroy(h)
             except Exception:
                 pass
+
+    def __del__(self):
+        self.close()
 
     def workspace(self, key, nbytes):
         t = self._ws.get(key)
@@ -57,13 +64,44 @@ def _f32(t):
     return t
 
 
-class ResnetStage:
-    """ResNet-50-cubic + CAM of ``model`` (model/resnet_cubic.py: ResNet) behind cp360_resnet_forward."""
+def _load_retry(call):
+    """``call()`` -> status of a cp360_*_load.  The library's only hipMallocs happen there; when one fails while torch's
+    caching allocator sits on freed blocks, release them and try once more."""
+    rc = call()
+    if rc == -7:                                           # CP360_ERR_HIP
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        rc = call()
+    check(rc)
 
-    def __init__(self, model):
-        self.model = model
+
+class _Stage:
+    """Common part of the two stage objects.  The module is held WEAKLY: the module keeps its stage in
+    ``module.__dict__['_stage']``, so a strong back reference would be a cycle and ``del engine`` would free nothing
+    (f32 parameters, the context's packed weights, the workspaces) until the cyclic collector runs."""
+
+    def __init__(self, module):
+        self._module = weakref.ref(module)
         self.ctx = None
         self.stamp = None
+
+    def _mod(self):
+        m = self._module()
+        if m is None:
+            raise RuntimeError("the module of this stage context is gone")
+        return m
+
+    def close(self):
+        """Release the context (packed weights, workspaces) now; the next call re-packs."""
+        ctx, self.ctx, self.stamp = self.ctx, None, None
+        if ctx is not None:
+            ctx.close()
+
+
+class ResnetStage(_Stage):
+    """ResNet-50-cubic + CAM of ``model`` (model/resnet_cubic.py: ResNet) behind cp360_resnet_forward."""
+
+    model = property(_Stage._mod)
 
     def _load(self):
         m = self.model
@@ -90,8 +128,8 @@ class ResnetStage:
         arr = (ConvBn * len(pairs))(*pairs)
         fc = _f32(m.fc.weight)
         mn = float(fc.min())                               # class_activation_model.py:51-52 (one host sync per load)
-        check(lib().cp360_resnet_load(self.ctx.h, dtype_code(precision_dtype(m.precision)), arr, len(pairs), ptr(fc),
-                                      int(fc.shape[0]), mn if mn < 0 else 0.0, float(eps), stream()))
+        _load_retry(lambda: lib().cp360_resnet_load(self.ctx.h, dtype_code(precision_dtype(m.precision)), arr, len(pairs), ptr(fc),
+                                                    int(fc.shape[0]), mn if mn < 0 else 0.0, float(eps), stream()))
         torch.cuda.current_stream().synchronize()          # the f32 sources (possibly temporaries) may go now
         self.stamp = stamp
 
@@ -121,13 +159,10 @@ class ResnetStage:
         return cam_out.view(-1)[:need].view(n_img, hw, hw, nc), feat
 
 
-class ClstmStage:
+class ClstmStage(_Stage):
     """``ConvLSTMCell`` (model/clstm.py) behind cp360_clstm_step, for one face size."""
 
-    def __init__(self, cell):
-        self.cell = cell
-        self.ctx = None
-        self.stamp = None
+    cell = property(_Stage._mod)
 
     def _load(self, face):
         c = self.cell
@@ -139,8 +174,8 @@ class ClstmStage:
         if self.ctx is None or self.ctx.device != dev:
             self.ctx = StageCtx(dev)
         ts = [_f32(t) for t in (c.Conv1.weight, c.Conv1.bias, c.Conv2.weight, c.Conv2.bias, c.Gates.weight, c.Gates.bias)]
-        check(lib().cp360_clstm_load(self.ctx.h, dtype_code(precision_dtype(c.precision)), *[ptr(t) for t in ts],
-                                     int(c.input_size), int(c.hidden_size), int(face), stream()))
+        _load_retry(lambda: lib().cp360_clstm_load(self.ctx.h, dtype_code(precision_dtype(c.precision)), *[ptr(t) for t in ts],
+                                                   int(c.input_size), int(c.hidden_size), int(face), stream()))
         torch.cuda.current_stream().synchronize()
         self.stamp = stamp
 

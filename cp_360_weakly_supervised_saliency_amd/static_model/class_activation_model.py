@@ -27,12 +27,10 @@ def cam_device(input_cubemap_nhwc4, model, out=None, padded=False, want_feat=Tru
     feat = model.features_nhwc(input_cubemap_nhwc4, padded)      # padded: the faces already carry their CubePad(3) ring
     cam = model.cam_conv()
     n6, h, w, _ = feat.shape
-    # splits = 1 + raw f32 output: the CAM has no bias / activation, and its scores feed
-    # the f32 window normalisation, so they are kept in f32 even on the bf16 path.
-    # ``out`` (f32, >= n6*h*w*1000 elements) lets the caller place them (e.g. straight
-    # into the clip buffer the ConvLSTM stage reads).
-    partial, _ = cam(feat, raw_f32=True, splits=1, partial_buf=None if out is None else out.view(-1))
-    score = partial[: n6 * h * w * cam.c_out].view(n6, h, w, cam.c_out)
+    # raw f32 output: the CAM has no bias / activation, and its scores feed the f32 window
+    # normalisation, so they are kept in f32 even on the bf16 path.  ``out`` (f32, >= n6*h*w*1000
+    # elements) lets the caller place them (e.g. straight into the clip buffer the ConvLSTM stage reads).
+    score = cam.raw_sum_f32(feat, None if out is None else out.view(-1))
     return score, feat
 
 

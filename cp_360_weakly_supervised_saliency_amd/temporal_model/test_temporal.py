@@ -26,6 +26,9 @@ class ClipRunner:
         from .. import stage_ctx
         self.a = None if stage_ctx.USE_CTX else [torch.empty((n6, w, w, 4 * ch), dtype=dt, device=dev) for _ in range(2)]
         self.minmax = torch.empty((self.B, 2), dtype=torch.float32, device=dev)
+        # measurement hook (bench.py stage_split, never set on the hot path): a list that receives three HIP events of the
+        # launch stream - before the window, after its last cell update, after cube -> equi + channel max
+        self.stage_events = None
         self.scratch = torch.empty((self.B * 256 * 2,), dtype=torch.float32, device=dev)
 
     def run(self, cam, return_hidden=False, sliding=False, return_all_steps=False):
@@ -47,6 +50,13 @@ class ClipRunner:
             raise ValueError("a sliding run over %d windows of %d frames needs %d frames" % (B, T, B + T - 1))
         stride = P * cin if sliding else 0
         from .. import stage_ctx
+
+        def mark():
+            if self.stage_events is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                self.stage_events.append(e)
+        mark()
         if stage_ctx.USE_CTX:
             # the whole window in ONE C call (cp360_clstm_window, csrc/ctx.hip): min / max, initial state, T cell updates -
             # and, with at most two windows per call, Conv1's x half batched over all T frames
@@ -57,10 +67,12 @@ class ClipRunner:
             if return_all_steps:
                 h_all = torch.empty((T,) + tuple(self.h_f32.shape), dtype=torch.float32, device=self.h_f32.device)
             stage.window(cam, B, T, self.w, self.xh, self.c, self.h_f32, self.minmax, self.scratch, clip_stride=stride, h_all=h_all)
+            mark()
             if return_all_steps:
                 sal = torch.stack([self.c2e.saliency(h_all[t], layout='nhwc') for t in range(T)], dim=1)
             else:
                 sal = self.c2e.saliency(self.h_f32, layout='nhwc')
+            mark()
             return (sal, self.h_f32) if return_hidden else sal
         ops.window_minmax(cam, B, T * P * cin, self.minmax, self.scratch, stride)
         # hidden = cell = (frame0 - mn) / (mx - mn)
@@ -77,7 +89,9 @@ class ClipRunner:
             cur ^= 1
             if return_all_steps:
                 steps.append(self.c2e.saliency(self.h_f32, layout='nhwc'))
+        mark()
         sal = torch.stack(steps, dim=1) if return_all_steps else self.c2e.saliency(self.h_f32, layout='nhwc')
+        mark()
         return (sal, self.h_f32) if return_hidden else sal
 
 

@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 303
+#define CP360_VERSION 304
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -176,7 +176,10 @@ typedef struct {
                          256 (tuning, tests): 128 / 256 / 304 force the pixel tile
                          of the 8-wave 256-channel kernels (129 = the 256x128 short-K
                          kernel that runs two workgroups per CU), 64 forces the
-                         4-wave 128x128 kernel                                    */
+                         4-wave 128x128 kernel; any c_out % 8 == 0: 6464 forces the
+                         64 x 64-tile small-M kernel (csrc/conv_small.hip), which the
+                         planner picks by itself for f32 launches that cannot fill the
+                         chip with the big tiles (one frame = 6 faces: BASELINE C2)  */
     int clip_resident;/* 1: CubePad(1) + 3x3 stride-1 convolution on cube faces small
                          enough that a whole cube (6 n^2 <= 304 pixels, n <= 7: the
                          ConvLSTM of model/clstm.py at cube size 224) is one tile:
@@ -207,6 +210,11 @@ typedef struct {
 size_t cp360_conv_packed_bytes(const cp360_conv_desc* d);
 /* Split-K factor (>= 1) that fills the 256 CUs for this geometry (d->splits ignored). */
 int cp360_conv_suggest_splits(const cp360_conv_desc* d);
+/* With BOTH weight layouts at hand (tap-major and clip-resident): 1 = launch this descriptor's geometry on the
+ * clip-resident kernel, 0 = on the tap-major path (whose planner then picks the 64 x 64-tile kernel: few cubes and few
+ * output channels, e.g. layer4's conv2 of ONE frame in f32, give the clip kernel 2 tiles for 256 CUs).  d->clip_resident
+ * and d->splits are ignored. */
+int cp360_conv_prefer_clip(const cp360_conv_desc* d);
 /* Bytes of split-K workspace (0 when splits == 1). */
 size_t cp360_conv_partial_bytes(const cp360_conv_desc* d);
 /* Pack OIHW f32 weights [c_out, c_in_w, kh_w, kw_w] times scale[c_out] (BatchNorm
@@ -519,14 +527,21 @@ int cp360_clstm_step(cp360_ctx* ctx, void* xh, const float* c_prev, float* c_nex
  *   h_out     f32 [6 n_clips, face, face, H]: the final hidden state (:80);  h_all (optional) f32 [T, 6 n_clips, face, face, H]:
  *             the hidden state after EVERY step (return_all_steps)
  *   minmax    f32 [n_clips, 2] (out), mm_scratch f32 [n_clips * 512]
- * Needs Cin == H (:70-73).  Planning inside: with at most two windows per call the ConvLSTM convolutions are weight-stream
- * bound, and the x half of Conv1 (K = 9 Cin, no recurrence) runs ONCE for all T frames (one M = T * 6 face^2 * n_clips GEMM without
- * split-K; its f32 result joins the h half's split-K slabs in cp360_conv_finish_add): Conv1's x weights stream once per window
- * instead of T times.  CP360_XBATCH=0 / 1 forces it off / on.  workspace: cp360_clstm_window_workspace_bytes. */
+ * Needs Cin == H (:70-73).  By default the window issues exactly the launches of T cp360_clstm_step calls (same bits).
+ * Opt-in, CP360_XBATCH=1 (measured performance-neutral; it changes Conv1's accumulation order): the x half of Conv1
+ * (K = 9 Cin, no recurrence) runs ONCE for all T frames (one M = T * 6 face^2 * n_clips GEMM without split-K; its f32 result
+ * joins the h half's split-K slabs in cp360_conv_finish_add), so Conv1's x weights stream once per window instead of T
+ * times, at T * M * 4H * 4 bytes more workspace.  workspace: cp360_clstm_window_workspace_bytes. */
 size_t cp360_clstm_window_workspace_bytes(cp360_ctx* ctx, int n_clips, int T, int face);
 int cp360_clstm_window(cp360_ctx* ctx, const float* cam, size_t clip_stride, int n_clips, int T, int face, void* xh,
                        float* cell0, float* cell1, float* h_out, float* h_all, float* minmax, float* mm_scratch,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* Diagnostic only (bench.py `held_clock_ghz`): a bare bf16 MFMA loop on pseudo-random operands, n_workgroups x 4 waves, each
+ * wave stamped once around `iters` x 16 MFMAs.  stamps: device u64 [n_workgroups * 4][2] = {d s_memtime (shader cycles),
+ * d s_memrealtime (100 MHz ticks)} per wave; held clock of a wave = 0.1 GHz * [0] / [1].  A buffer of its own: no output of
+ * the library depends on it. */
+int cp360_clock_probe(unsigned long long* stamps, int n_workgroups, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the oracle's two CPU hot spots at several torch thread counts (picks the
 thread count the cpu_baseline leg of bench.py should use on this host)."""
 import os, sys, time

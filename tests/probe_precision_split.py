@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where does the 16-bit error of the saliency map come from?  One 1024x2048 T=16 clip through the
 oracle (fp32 CPU) and through the HIP path with the static stage (ResNet + CAM) and the temporal stage
 (ConvLSTM) in separately chosen arithmetic types.  Prints max|d|, mean d, CC(build, oracle), dAUC, dCC."""

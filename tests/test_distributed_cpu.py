@@ -117,3 +117,40 @@ def test_torchrun_launcher_contract(n_clips):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['clips'] == n_clips and out['gathered_equal_single_process'] is True
     assert out['max_elapsed'] == 1.5 and out['backend'] == 'gloo'
+
+
+@pytest.mark.parametrize('world', [2, 1])
+def test_bench_py_main_under_the_launcher_with_the_stub_engine(world):
+    """bench.py ITSELF (not a look-alike worker) started the way the driver starts it for N > 1 - ``python -m
+    torch.distributed.run --nproc-per-node N bench.py --gpus N --steps K --warmup W`` - with ``--stub-engine`` (CPU tensors,
+    gloo, a stand-in for the HIP engine): argument handling, init_from_env, the per-rank clips, the all-gather, the
+    max-over-ranks timing and every key of the one JSON line are exercised, so the first real multi-GPU run cannot die on a
+    key error (8-GPU hardware is the driver's)."""
+    import json
+    import subprocess
+    clips, frames, steps, warmup = 3, 2, 2, 1
+    tail = [os.path.join(REPO, 'bench.py'), '--gpus', str(world), '--steps', str(steps), '--warmup', str(warmup), '--stub-engine',
+            '--clips', str(clips), '--frames', str(frames), '--equi', '64x128', '--cube', '64']
+    if world > 1:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout                     # exactly one line, from rank 0
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == world and out['steps'] == steps and out['warmup'] == warmup
+    assert out['stub_engine'] is True and out['data'] == 'stub' and out['scaling'] == 'weak' and out['higher_is_better'] is True
+    assert len(out['ms_per_step_per_rank']) == world
+    assert out['map_shape'] == [world * clips, 4, 8]      # every rank's clips gathered: [N * clips, 2w, 4w], w = 64 / 32
+    assert out['value'] > 0 and abs(out['value'] - world * clips * frames / (out['ms_per_step'] * 1e-3)) <= 0.01 * out['value']
+    assert out['allgather_ms'] >= 0 and out['allgather_bytes_per_rank'] == clips * 4 * 8 * 4
+    assert out['roofline'] is None and out['cpu_baseline'] is None and 'secondary' not in out
+    assert out['held_clock_ghz'] is None and out['stage_ms'] is None
+    for key in ('metric', 'unit', 'vs_baseline', 'dtype', 'config'):
+        assert key in out

@@ -293,9 +293,56 @@ def test_conv_matches_torch_cpu(case, prec):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
+@pytest.mark.parametrize('raw', [False, True])
+def test_conv_small_tile_matches_torch_cpu(case, prec, raw):
+    """tile_px = 6464: the 64 x 64-tile small-M kernel (csrc/conv_small.hip; what BASELINE config C2 - one frame = 6 faces,
+    fp32 - runs layers 1-4 and the CAM on) over the same cases as the generic kernels: narrow / ragged channel tiles, the
+    residual epilogue, fused CubePad with stride, strided 1x1, K tails, split-K slabs (packed-row column order) + finish,
+    c_out = 1000; raw: the f32 sums in true channel order (how the CAM scores leave, class_activation_model.py:77-83)."""
+    n_img, cin, cout, n, k, stride, pad, relu, use_res, splits = case
+    dt = _TDT[prec]
+    seed = 9000 + cin + cout
+    x = hashrng.normal(seed, (n_img, cin, n, n))
+    w = hashrng.normal(seed + 1, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
+    scale = hashrng.uniform(seed + 2, (cout,), 0.5, 1.5)
+    bias = hashrng.normal(seed + 3, (cout,), 0, 0.1)
+    ho = (n + 2 * pad - k) // stride + 1
+    res = hashrng.normal(seed + 4, (n_img, cout, ho, ho)) if use_res and not raw else None
+    rb = (lambda a: torch.from_numpy(a).to(dt).float().numpy()) if prec != 'fp32' else (lambda a: a)
+    w_ref = rb((w * scale[:, None, None, None]).astype(np.float32))
+    want = _conv_ref(rb(x), w_ref, None, None if raw else bias, stride, pad, relu and not raw, None if res is None else rb(res))
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), stride, pad, relu, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    rt = None if res is None else ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
+    if raw:
+        part, ns = conv(xt, raw_f32=True, splits=splits or 1, tile_px=6464)
+        got = part[:ns * n_img * ho * ho * cout].view(ns, n_img, ho, ho, cout).sum(0).permute(0, 3, 1, 2).cpu().numpy()
+        tol = 2e-5 if prec == 'fp32' else 1e-4                     # no output rounding: only the summation order differs
+    else:
+        got = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits, tile_px=6464), out_dtype=torch.float32).cpu().numpy()
+        tol = _TOL[prec]
+    assert got.shape == want.shape
+    assert rel_err(got, want) <= tol, rel_err(got, want)
+
+
+def test_conv_small_tile_is_what_one_frame_fp32_runs():
+    """The launch planner picks the small tile by itself for fp32 launches that cannot fill the chip (M = 294 .. 4704 pixels,
+    one frame), not for the 64-frame batches: same result as the forced tile bit for bit at 6 faces, and the suggested split
+    count differs between 6 and 384 faces (different kernels were planned)."""
+    cin, cout, n = 1024, 256, 14
+    w = hashrng.normal(9701, (cout, cin, 1, 1), 0, (2.0 / cin) ** 0.5)
+    conv = ops.Conv(torch.from_numpy(w), None, torch.zeros(cout), 1, 0, True, torch.float32, DEV)
+    x = torch.from_numpy(hashrng.normal(9700, (6, n, n, cin))).to(DEV)
+    auto, forced = conv(x), conv(x, tile_px=6464, splits=conv._splits_cache[(6, n, n, 0)])
+    assert torch.equal(auto, forced)
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('geom', [(64, 64, 256, 14, 1, 0), (96, 200, 264, 14, 2, 0), (128, 256, 512, 10, 2, 304),
-                                  (512, 1024, 2048, 7, 1, 256), (64, 64, 256, 9, 1, 3)])
+                                  (512, 1024, 2048, 7, 1, 256), (64, 64, 256, 9, 1, 3), (96, 200, 264, 14, 2, 6464),
+                                  (512, 1024, 2048, 7, 1, 6464)])
 def test_conv_second_source_downsample_fused(prec, geom):
     """cp360_conv_desc.c_in2: out = relu(W3 . mid + b3 + Wd . x[::s, ::s] + bd) in one tile = conv3 + bn3 +
     downsample(conv1x1 stride s + bn) + add + relu of a Bottleneck's first block (resnet_cubic.py:85-106),

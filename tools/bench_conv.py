@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Micro-benchmark of the implicit-GEMM convolution on the shapes of the path
 (GPU box).  Prints avg launch time (HIP events over back-to-back launches) and TFLOP/s.
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Source patches for tools/exp_build.sh (timing experiments on the convolution kernels; see there).
 The patches are textual: a variant asserts if the code it rewrites has changed since it was written
 (`base` always builds)."""

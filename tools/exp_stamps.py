@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where does a sub-step of the clip kernel spend its cycles?  Runs the ConvLSTM Conv2 shape on a library built with
 `tools/exp_build.sh clip_stamps` (CP360_LIB=...) and prints, per wave, the mean s_memtime cycles of the five
 intervals of a sub-step: [vmcnt wait + loop] [barrier 1] [first half: HEAD (waves 0-3) / TAIL (4-7)] [barrier 2]

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """HBM-bound kernels of the path, one by one, at the shapes of the benchmark step (4 clips x 16 frames of
 1024x2048, cube 224, 16-bit static stage): algorithmic bytes, microseconds, GB/s and the fraction of the 8 TB/s
 HBM3E peak (MI355X_MICROARCH.md; ~6.3 TB/s is what a float4 copy reaches).  Times are HIP-event averages over

@@ -1,6 +1,11 @@
-#!/usr/bin/env python3
 """K1 (equi2cube, 64 frames 1024x2048 u8 -> padded f16 faces) alone, a few launches: for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-passes with the CP360_E2C_FU / CP360_E2C_CAP switches (tools/_run.sh).  Prints the HIP-event time per launch."""
+passes with the CP360_E2C_FU / CP360_E2C_CAP switches.  Prints the HIP-event time per launch.
+
+Under the profiler put the interpreter itself after ``--`` (never ``env``, a shell or this file as an executable: the profiler's
+preloaded library has initialised the GPU by then and such a hop is an exec the pool forbids):
+
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/k1_fetch -- python3 $R/tools/k1_probe.py
+"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

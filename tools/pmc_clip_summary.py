@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summary of the counter passes tools/pmc_clip_final.sh collected for the dominant kernel (conv_clip_kernel on the
 ConvLSTM Conv2 / Gates shape): per-launch averages and the derived ratios DESIGN.md quotes.
 

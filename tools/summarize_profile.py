@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Turn the rocprofv3 CSVs of tools/collect_profile.sh into the committed summary
 under profiles/: per-kernel time table (kernel-trace --stats) and per-launch HBM traffic
 of the dominant kernel from the PMC passes.
