@@ -146,6 +146,9 @@ __device__ __forceinline__ void unpack8(const u32x4& r, float v[8], f16_raw) {
     for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
 }
 
+// conv_small.hip keeps a [tap][tile row] source-offset table in LDS: kh * kw (+ 1 for a second source) must fit
+#define CP360_SMALL_MAX_TAPS 16
+
 // conv_small.hip: the 64 x 64-tile kernel for launches whose pixel count cannot fill the chip with the big tiles
 // (k.nt / k.mt / k.m_fast are set inside).  dtype: CP360_F32 / CP360_BF16 / CP360_F16.
 void cp360_launch_conv_small(ConvK& k, int dtype, hipStream_t st);

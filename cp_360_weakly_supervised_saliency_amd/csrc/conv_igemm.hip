@@ -1525,7 +1525,8 @@ static int check_desc(const cp360_conv_desc* d) {
     if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 256 &&
         d->tile_px != 304 && d->tile_px != 6464)
         return CP360_ERR_BAD_SHAPE;
-    if (d->tile_px == 6464 && (d->clip_resident || d->c_out % 8 != 0)) return CP360_ERR_UNSUPPORTED;   // conv_small.hip
+    if (d->tile_px == 6464 && (d->clip_resident || d->c_out % 8 != 0 || d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS))
+        return CP360_ERR_UNSUPPORTED;                                                                    // conv_small.hip
     if (d->tile_px == 129 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;   // 16-bit types only (128-VGPR budget)
     if (d->slab_rows != 0 && d->slab_rows != 1) return CP360_ERR_BAD_SHAPE;
     if (d->slab_rows && d->c_out % 32 != 0) return CP360_ERR_ALIGN;
@@ -1614,6 +1615,7 @@ static bool small_eligible(const cp360_conv_desc* d) {
         return e ? atoi(e) : 1;
     }();
     if (!small || d->clip_resident || d->c_out % 8 != 0) return false;
+    if (d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS) return false;
     if (d->dtype != CP360_F32) {
         if (small < 2) return false;
         if (d->ld_out % 8 != 0 || d->out_coff % 8 != 0 || d->ld_res % 8 != 0) return false;

@@ -45,11 +45,12 @@ __device__ __forceinline__ void mma_step(f32x4 (&acc)[2][2], const u32x4 (&a)[2]
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void conv_small_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
     constexpr int BN = 64, BM = 64;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;                        // 128 bytes of K per tile row and step
     constexpr int STAGE = (BN + BM) * 128;
+    constexpr int MAX_TAPS = CP360_SMALL_MAX_TAPS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,46 +80,49 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(const ConvK p) {
     }
     const int chunk = tid & 7, row0 = tid >> 3;
 
-    // ---- this thread's two activation rows: (image, face, oy, ox) once - the divisions happen here, not per tap
-    int rimg[2], rface[2], roy[2], rox[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        const int m = m0 + row0 + 32 * pb;
-        rimg[pb] = -1; rface[pb] = 0; roy[pb] = 0; rox[pb] = 0;
-        if (m < p.M) {
-            const int img = m / p.hw_out, rem = m - img * p.hw_out;
-            const int oy = rem / p.w_out;
-            rimg[pb] = img;
-            rface[pb] = img - (img / 6) * 6;
-            roy[pb] = oy;
-            rox[pb] = rem - oy * p.w_out;
+    // ---- source-offset table: element offset of tile row r's input pixel for tap t, offtab[t * 64 + r] (-1: no such output
+    // pixel).  All divisions and the branchy cubepad_src() run HERE, once per (tap, row); inside the K loop a tap change is
+    // two LDS reads per thread.  (Computed in the loop - as conv_igemm_kernel does - the divergent code and the waits the
+    // compiler merges at its join points cost more than the MFMAs of a 64 x 64 tile: 0.94 us per f32 K step against 0.45.)
+    __shared__ int offtab[MAX_TAPS * BM];
+    {
+        const int ntap_all = p.ntap + (p.c_in2 > 0 ? 1 : 0);
+        const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
+        for (int t = tid; t < ntap_all * BM; t += 256) {
+            const int tp = t >> 6, r = t & 63;
+            const int m = m0 + r;
+            int off = -1;
+            if (m < p.M) {
+                const int img = m / p.hw_out, rem = m - img * p.hw_out;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                if (tp >= p.ntap) {
+                    off = ((img * p.h_in2 + oy * p.sy2) * p.w_in2 + ox * p.sx2) * p.pix_stride2;
+                } else {
+                    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+                    const int py = oy * p.sy + ky, px = ox * p.sx + kx;
+                    int pix;
+                    if (p.pad_mode) {
+                        const int grp = img / 6, f = img - grp * 6;
+                        pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
+                    } else {
+                        pix = (img * p.h_in + py) * p.w_in + px;
+                    }
+                    off = pix * p.pix_stride;
+                }
+            }
+            offtab[t] = off;
         }
     }
+    __syncthreads();
     const T* in = reinterpret_cast<const T*>(p.in);
     const T* in2 = reinterpret_cast<const T*>(p.in2);
     const T* src = in;                                 // tensor of the current tap (the second source for tap == ntap)
     int src_cin = p.c_in, src_cpad = p.c_pad;
     int roff[2];
-    const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
     auto set_tap = [&](int tap) __attribute__((always_inline)) {
         const bool second = tap >= p.ntap;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            int off = -1;
-            if (rimg[pb] >= 0) {
-                if (second) {
-                    off = ((rimg[pb] * p.h_in2 + roy[pb] * p.sy2) * p.w_in2 + rox[pb] * p.sx2) * p.pix_stride2;
-                } else {
-                    const int py = roy[pb] * p.sy + ky, px = rox[pb] * p.sx + kx;
-                    int pix;
-                    if (p.pad_mode) pix = (rimg[pb] - rface[pb]) * p.h_in * p.w_in + cubepad_src(rface[pb], py, px, geom);
-                    else pix = (rimg[pb] * p.h_in + py) * p.w_in + px;
-                    off = pix * p.pix_stride;
-                }
-            }
-            roff[pb] = off;
-        }
+        roff[0] = offtab[tap * BM + row0];
+        roff[1] = offtab[tap * BM + row0 + 32];
         src = second ? in2 : in;
         src_cin = second ? p.c_in2 : p.c_in;
         src_cpad = second ? p.c_pad2 : p.c_pad;
@@ -140,26 +144,39 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(const ConvK p) {
 
     // Pipeline.  Iteration `it` computes K step `it` from fragments that are already in registers:
     //   barrier -> read the fragments of step it+1 (LDS buffer (it+1) & 1) into the OTHER fragment set -> store the staged
-    //   global data of step it+2 into buffer it & 1 (every wave's reads of that buffer completed before the barrier:
-    //   __syncthreads drains lgkmcnt) -> request step it+3 from global memory into the staging registers just freed ->
-    //   the 32 (f32) MFMAs of step it.
+    //   global data of step it+2 (staging set it & 1) into buffer it & 1 (every wave's reads of that buffer completed before
+    //   the barrier: __syncthreads drains lgkmcnt, not vmcnt) -> request step it+4 from global memory into the staging set
+    //   just freed -> the 32 (f32) MFMAs of step it.
     // So the matrix pipe never waits for LDS (a step's fragments are requested one whole MFMA phase before their use) and a
-    // global load has a phase to land; one wave per SIMD keeps its pipe busy without a partner.
-    u32x4 ra[2], rb[2];                                   // staging: one K step of this thread's 2 + 2 tile-row chunks
-    auto gload = [&]() __attribute__((always_inline)) {
+    // global load has TWO phases to land (one was not enough: activations the previous launch has just written come from
+    // another XCD's L2 / the Infinity Cache, > 1000 cycles under load); one wave per SIMD keeps its pipe busy without a
+    // partner.  The body is unconditional: past the last step the loads repeat the last step's addresses and nobody reads
+    // what they bring (four redundant 64-byte loads per thread against a branch-free loop).
+    u32x4 ra0[2], rb0[2], ra1[2], rb1[2];                 // two staging sets: one K step of this thread's 2 + 2 tile-row chunks each
+    // address of the zero page, pinned in a VGPR pair: rematerialised inside the loop it is a scalar load per step whose
+    // lgkmcnt(0) wait also drains the fragment reads just issued
+    unsigned long long z = (unsigned long long)reinterpret_cast<size_t>(g_zero16);
+    asm volatile("" : "+v"(z));
+    auto gload = [&](u32x4 (&ra)[2], u32x4 (&rb)[2]) __attribute__((always_inline)) {
         const int e = c0 + chunk * EPC;
         const size_t koff = (size_t)tap * p.c_pad + c0;
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa) ra[pa] = *reinterpret_cast<const u32x4*>(wbase + pa * wpass + koff);
-        const bool kval = e < src_cin;
+        // invalid rows (no such output pixel) and the K tail read the 16 zero bytes of g_zero16.  The select is done with a
+        // mask on the address difference, not "ok ? a : z": the compiler turned that into a divergent branch on the K-tail
+        // test whose join waits for vmcnt(0) - the weight loads just issued - in front of every step's MFMAs
+        const int ktail = (e - src_cin) >> 31;            // all ones while e < src_cin
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
-            const bool ok = kval && roff[pb] >= 0;
-            const T* s = ok ? src + (size_t)roff[pb] + e : reinterpret_cast<const T*>(g_zero16);
-            rb[pb] = *reinterpret_cast<const u32x4*>(s);
+            const long long mask = (long long)(ktail & ~(roff[pb] >> 31));
+            const unsigned long long a = (unsigned long long)reinterpret_cast<size_t>(src + (size_t)(roff[pb] & 0x7fffffff) + e);
+            // (an explicit global-address-space pointer: from a plain integer the compiler makes a FLAT load, which also
+            // counts in lgkmcnt - the next barrier's LDS drain would then wait for it)
+            typedef const u32x4 __attribute__((address_space(1)))* gptr_t;
+            rb[pb] = *reinterpret_cast<gptr_t>(z + ((a - z) & (unsigned long long)mask));
         }
     };
-    auto lds_store = [&](int buf) __attribute__((always_inline)) {
+    auto lds_store = [&](int buf, const u32x4 (&ra)[2], const u32x4 (&rb)[2]) __attribute__((always_inline)) {
         unsigned char* As = lds + buf * STAGE;
         unsigned char* Bs = As + BN * 128;
 #pragma unroll
@@ -167,13 +184,22 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(const ConvK p) {
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) *reinterpret_cast<u32x4*>(Bs + lds_swz(row0 + 32 * pb, chunk)) = rb[pb];
     };
-    auto advance = [&]() __attribute__((always_inline)) {
-        c0 += BK;
-        if (c0 >= src_cpad) {
-            c0 = 0;
-            ++tap;
-            set_tap(tap);
+    const int nloc = s_end - s_begin;
+    int issued = 0;                                       // K steps requested so far
+    auto next_gload = [&](u32x4 (&ra)[2], u32x4 (&rb)[2]) __attribute__((always_inline)) {
+        if (issued > 0 && issued < nloc) {                // (uniform) move on to the next step; past the end: repeat the last
+            c0 += BK;
+            if (c0 >= src_cpad) {
+                c0 = 0;
+                ++tap;
+                set_tap(tap);
+            }
         }
+        ++issued;
+        gload(ra, rb);
+        // keep the requests HERE, in front of the step's MFMAs: left alone the scheduler sinks them past the MFMAs to just
+        // before the barrier, where the LDS store right behind it waits out their whole latency every step
+        __builtin_amdgcn_sched_barrier(0);
     };
     const int lrow = lane & 15, lchunk = lane >> 4;
     auto frag_load = [&](int buf, u32x4 (&a)[2][2], u32x4 (&b)[2][2]) __attribute__((always_inline)) {
@@ -196,49 +222,33 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(const ConvK p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nloc = s_end - s_begin;
     if (nloc > 0) {
         u32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
         set_tap(tap);
-        gload();                                         // step 0
-        lds_store(0);
-        if (nloc > 1) {
-            advance();
-            gload();                                     // step 1
-        }
+        next_gload(ra0, rb0);                            // step 0
+        next_gload(ra1, rb1);                            // step 1
+        lds_store(0, ra0, rb0);
+        next_gload(ra0, rb0);                            // step 2
         __syncthreads();
         frag_load(0, fa0, fb0);
-        if (nloc > 1) lds_store(1);
-        if (nloc > 2) {
-            advance();
-            gload();                                     // step 2
-        }
-        int it = 0;
-        while (true) {
-            // even step: fragments in set 0 (buffer 0)
-            if (it + 1 < nloc) {
-                __syncthreads();
-                frag_load(1, fa1, fb1);
-                if (it + 2 < nloc) lds_store(0);
-                if (it + 3 < nloc) {
-                    advance();
-                    gload();
-                }
-            }
+        lds_store(1, ra1, rb1);
+        next_gload(ra1, rb1);                            // step 3
+        for (int it = 0; it < nloc; it += 2) {
+            // even step: its fragments are in set 0; buffer 1 holds step it+1, staging set 0 step it+2, set 1 (in flight) it+3
+            __syncthreads();
+            frag_load(1, fa1, fb1);
+            lds_store(0, ra0, rb0);
+            next_gload(ra0, rb0);                        // step it+4
             mma_step<T>(acc, fa0, fb0);
-            if (++it >= nloc) break;
-            // odd step: fragments in set 1 (buffer 1)
-            if (it + 1 < nloc) {
-                __syncthreads();
-                frag_load(0, fa0, fb0);
-                if (it + 2 < nloc) lds_store(1);
-                if (it + 3 < nloc) {
-                    advance();
-                    gload();
-                }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 >= nloc) break;
+            // odd step
+            __syncthreads();
+            frag_load(0, fa0, fb0);
+            lds_store(1, ra1, rb1);
+            next_gload(ra1, rb1);                        // step it+5
             mma_step<T>(acc, fa1, fb1);
-            if (++it >= nloc) break;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
