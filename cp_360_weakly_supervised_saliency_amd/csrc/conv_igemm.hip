@@ -1525,7 +1525,9 @@ static int check_desc(const cp360_conv_desc* d) {
     if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 256 &&
         d->tile_px != 304 && d->tile_px != 6464)
         return CP360_ERR_BAD_SHAPE;
-    if (d->tile_px == 6464 && (d->clip_resident || d->c_out % 8 != 0 || d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS))
+    if (d->tile_px == 6464 && (d->clip_resident || d->c_out % 8 != 0 || d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS ||
+                               (long long)d->n_img * d->h_in * d->w_in * d->pix_stride * elem_bytes(d->dtype) >= (1LL << 32) ||
+                               (d->c_in2 > 0 && (long long)d->n_img * d->h_in2 * d->w_in2 * d->pix_stride2 * elem_bytes(d->dtype) >= (1LL << 32))))
         return CP360_ERR_UNSUPPORTED;                                                                    // conv_small.hip
     if (d->tile_px == 129 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;   // 16-bit types only (128-VGPR budget)
     if (d->slab_rows != 0 && d->slab_rows != 1) return CP360_ERR_BAD_SHAPE;
@@ -1606,9 +1608,10 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
     return best;
 }
 
-// conv_small.hip: 64 x 64 tiles, 4 waves, up to four workgroups per CU.  f32 steps are MFMA-bound (1024 cycles per SIMD
-// for a 128-byte K step; workgroups that share a CU share its matrix pipes), so a launch costs about
-// (workgroups per CU) x steps x 0.5 us + a fixed 3 us per wave of 1024 workgroups.
+// conv_small.hip: 64 x 64 tiles, 8 waves, two workgroups per CU.  Measured on MI355X (tools/exp_small.sh, one frame): an f32
+// K step (128 bytes per tile row: 16 KB into the CU, 1024 MFMA cycles per SIMD) takes 0.70 us per workgroup on a CU - the
+// CU's ~10 bytes / clock of global-load throughput, not the matrix pipe (0.43 us), is what a step waits for - so a launch
+// costs about (workgroups per CU) x steps x 0.7 us + a fixed 3 us per wave of 1024 workgroups.
 static bool small_eligible(const cp360_conv_desc* d) {
     static const int small = []() {
         const char* e = getenv("CP360_SMALL");               // A/B switch: 0 = never, 1 = f32 only (default), 2 = every dtype
@@ -1616,6 +1619,11 @@ static bool small_eligible(const cp360_conv_desc* d) {
     }();
     if (!small || d->clip_resident || d->c_out % 8 != 0) return false;
     if (d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS) return false;
+    // 32-bit byte offsets inside the tensors and inside a tile's 64 weight rows
+    const long long es = elem_bytes(d->dtype);
+    if ((long long)d->n_img * d->h_in * d->w_in * d->pix_stride * es >= (1LL << 32)) return false;
+    if (d->c_in2 > 0 && (long long)d->n_img * d->h_in2 * d->w_in2 * d->pix_stride2 * es >= (1LL << 32)) return false;
+    if (64LL * ((long long)d->kh * d->kw * c_pad_of(d) + c_pad2_of(d)) * es >= (1LL << 32)) return false;
     if (d->dtype != CP360_F32) {
         if (small < 2) return false;
         if (d->ld_out % 8 != 0 || d->out_coff % 8 != 0 || d->ld_res % 8 != 0) return false;
@@ -1628,7 +1636,7 @@ static ConvPlan plan_small(const cp360_conv_desc* d) {
     const long long tiles = ((d->c_out + 63) / 64) * ((M + 63) / 64);
     const int bk = bk_of(d->dtype);
     const int nsteps = d->kh * d->kw * (round_up(d->c_in, bk) / bk) + c_pad2_of(d) / bk;
-    const double t_step = d->dtype == CP360_F32 ? 0.5 : 0.2;
+    const double t_step = d->dtype == CP360_F32 ? 0.7 : 0.35;
     ConvPlan best{64, 64, 1024, 1, 0.0};
     for (int s = 1; s <= 32; ++s) {
         if (s > 1 && nsteps / s < 4) break;

@@ -1,4 +1,4 @@
-// K3 small-M form: implicit-GEMM convolution with a 64 (output channels) x 64 (pixels) tile per 4-wave workgroup.
+// K3 small-M form: implicit-GEMM convolution with a 64 (output channels) x 64 (pixels) tile per 8-wave workgroup.
 //
 // Why it exists (profiles/r04a_c2_fp32_static_timeline.md): the reference's static driver processes ONE frame = 6 cube
 // faces per iteration (static_model/dataset_feat_extractor.py:119-162, class_activation_model.py:55-83), so layers 2-4 of
@@ -6,55 +6,62 @@
 // conv_igemm.hip (256 x 128 ... 256 x 304, 8 waves) cut such a launch into 12-150 workgroups for 256 CUs, and in f32
 // (v_mfma_f32_16x16x4_f32: 32 cycles per SIMD for 1024 MACs) a 256 x 128 tile is 3.4 us PER 128-byte K step: the
 // launches were MFMA-bound on a sixth of the chip.  Here a tile is 1/8 of that, so the same launch gives 8x the
-// workgroups before any split-K, and a K step is 1024 cycles per SIMD.
+// workgroups before any split-K, and a K step is 1024 MFMA cycles per SIMD.
 //
-// Structure: register-staged global loads -> swizzled LDS (two buffers) -> fragments in registers one step AHEAD of the
-// MFMAs that use them (the pipeline comment in the kernel), one barrier per K step, wave tile 32 x 32 = 2 x 2 MFMA blocks.  With the acc_chan row order of the
-// packed weights the two row blocks of a wave give a lane EIGHT consecutive channels of one pixel: bias, residual,
-// ReLU, one rounding and the store (or the split-K slab store) are 16-byte pieces straight against global memory.
-// Supports everything the ring kernels do for the ResNet / CAM call sites: CubePad gather (cubepad_src) in the loader,
-// stride, the stem's pixel-run taps, split-K slabs (both column orders), raw f32 sums, and the second source (the
-// Bottleneck's downsample branch as one more 1x1 "tap" of conv3's K loop, resnet_cubic.py:99-100).
+// Structure.  Register-staged global loads (two steps ahead) -> swizzled LDS (two buffers) -> fragments -> MFMA, one
+// barrier per K step.  The 64 x 64 tile is four 32 x 32 wave tiles; EACH is computed by TWO waves that sit on the same
+// SIMD and split every 128-byte K step between them (waves 0-3 take its first 64 bytes, waves 4-7 the second; the two
+// accumulator sets are added through LDS once, after the K loop).  A first 4-wave version of this kernel spent 40 % of a
+// step outside the matrix pipe (barrier, fragment reads, LDS stores, address arithmetic, then 32 MFMAs, strictly in that
+// order: 0.86 us per f32 step against 0.46 of MFMA time) - with two waves per SIMD one wave's overhead runs under the
+// other's MFMAs, PROVIDED they are not in lockstep (MI355X_MICROARCH.md, "Two waves per SIMD", item 9): waves 4-7
+// therefore trail by one step - after the barrier they first multiply the fragments they fetched in the previous
+// iteration and do their loads afterwards, while waves 0-3 do their loads first and multiply afterwards.
+//
+// With the acc_chan row order of the packed weights the two row blocks of a wave give a lane EIGHT consecutive channels
+// of one pixel: bias, residual, ReLU, one rounding and the store (or the split-K slab store) are 16-byte pieces
+// straight against global memory.  Supports everything the ring kernels do for the ResNet / CAM call sites: CubePad
+// gather (cubepad_src) in the loader, stride, the stem's pixel-run taps, split-K slabs (both column orders), raw f32 sums,
+// and the second source (the Bottleneck's downsample branch as one more 1x1 "tap" of conv3's K loop,
+// resnet_cubic.py:99-100).
 #include "conv_common.h"
 
 namespace {
 
-// One K step of a wave's 32 x 32 tile.  f32: a lane's 16-byte chunk holds its four k values of four CONSECUTIVE
-// v_mfma_f32_16x16x4_f32 (k = 4 * (lane >> 4) + e); the four accumulators are walked inside the e loop so that two
-// MFMAs on the same accumulator are four issues apart (dependent latency 40 cycles against an issue interval of 32).
+// One wave's share of a K step: one 64-byte half (16 f32 / 32 16-bit k values) of its 32 x 32 tile.  f32: a lane's 16-byte
+// chunk holds its four k values of four CONSECUTIVE v_mfma_f32_16x16x4_f32 (k = 4 * (lane >> 4) + e); the four accumulators
+// are walked inside the e loop, so two MFMAs on the same accumulator are four issues apart.
 template <typename T>
-__device__ __forceinline__ void mma_step(f32x4 (&acc)[2][2], const u32x4 (&a)[2][2], const u32x4 (&b)[2][2]) {
+__device__ __forceinline__ void mma_half(f32x4 (&acc)[2][2], const u32x4 (&a)[2], const u32x4 (&b)[2]) {
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        if constexpr (sizeof(T) == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[kk][i][e]), __uint_as_float(b[kk][j][e]),
-                                                                         acc[i][j], 0, 0, 0);
-        } else {
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma_chunk<T>(acc[i][j], a[kk][i], b[kk][j]);
-        }
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]), acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_chunk<T>(acc[i][j], a[i], b[j]);
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
-    constexpr int BN = 64, BM = 64;
+__global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvK p) {
+    constexpr int BN = 64, BM = 64, NT = 512;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;                        // 128 bytes of K per tile row and step
     constexpr int STAGE = (BN + BM) * 128;
     constexpr int MAX_TAPS = CP360_SMALL_MAX_TAPS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2;                        // 0: leads (loads, then MFMAs); 1: trails by one step (MFMAs, then loads)
+    const int wn = (wave >> 1) & 1, wm = wave & 1;
     // XCD-aware work mapping (as conv_igemm_kernel): every XCD takes a contiguous range of work items, ordered so that
     // neighbours share the larger operand panel through that XCD's L2.  Placement affects speed only.
     int n0, m0, split;
@@ -78,17 +85,17 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
         n0 = nt_i * BN;
         m0 = mt_i * BM;
     }
-    const int chunk = tid & 7, row0 = tid >> 3;
+    const int chunk = tid & 7, row0 = tid >> 3;        // this thread's 16-byte chunk of weight row row0 AND of pixel row row0
 
     // ---- source-offset table: element offset of tile row r's input pixel for tap t, offtab[t * 64 + r] (-1: no such output
     // pixel).  All divisions and the branchy cubepad_src() run HERE, once per (tap, row); inside the K loop a tap change is
-    // two LDS reads per thread.  (Computed in the loop - as conv_igemm_kernel does - the divergent code and the waits the
-    // compiler merges at its join points cost more than the MFMAs of a 64 x 64 tile: 0.94 us per f32 K step against 0.45.)
+    // one LDS read per thread.  (Computed in the loop - as conv_igemm_kernel does - the divergent code and the waits the
+    // compiler merges at its join points cost more than the MFMAs of a 64 x 64 tile.)
     __shared__ int offtab[MAX_TAPS * BM];
     {
         const int ntap_all = p.ntap + (p.c_in2 > 0 ? 1 : 0);
         const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
-        for (int t = tid; t < ntap_all * BM; t += 256) {
+        for (int t = tid; t < ntap_all * BM; t += NT) {
             const int tp = t >> 6, r = t & 63;
             const int m = m0 + r;
             int off = -1;
@@ -118,11 +125,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
     const T* in2 = reinterpret_cast<const T*>(p.in2);
     const T* src = in;                                 // tensor of the current tap (the second source for tap == ntap)
     int src_cin = p.c_in, src_cpad = p.c_pad;
-    int roff[2];
+    int roff;
+    unsigned avoff = 0;                                // byte offset of this thread's chunk inside the tap's pixel (0 for an invalid row)
     auto set_tap = [&](int tap) __attribute__((always_inline)) {
         const bool second = tap >= p.ntap;
-        roff[0] = offtab[tap * BM + row0];
-        roff[1] = offtab[tap * BM + row0 + 32];
+        roff = offtab[tap * BM + row0];
+        avoff = (unsigned)((roff < 0 ? 0 : roff) + chunk * EPC) * (unsigned)sizeof(T);
         src = second ? in2 : in;
         src_cin = second ? p.c_in2 : p.c_in;
         src_cpad = second ? p.c_pad2 : p.c_pad;
@@ -139,54 +147,51 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
         tap = p.ntap;
         c0 = (s_begin - first_steps) * BK;
     }
-    const T* wbase = reinterpret_cast<const T*>(p.w) + (size_t)(n0 + row0) * p.k_total + chunk * EPC;
-    const size_t wpass = (size_t)32 * p.k_total;
+    const unsigned wvoff = (unsigned)(row0 * p.k_total + chunk * EPC) * (unsigned)sizeof(T);     // this thread's chunk inside the tile's weight rows
+    const T* wtile = reinterpret_cast<const T*>(p.w) + (size_t)n0 * p.k_total;
 
-    // Pipeline.  Iteration `it` computes K step `it` from fragments that are already in registers:
-    //   barrier -> read the fragments of step it+1 (LDS buffer (it+1) & 1) into the OTHER fragment set -> store the staged
-    //   global data of step it+2 (staging set it & 1) into buffer it & 1 (every wave's reads of that buffer completed before
-    //   the barrier: __syncthreads drains lgkmcnt, not vmcnt) -> request step it+4 from global memory into the staging set
-    //   just freed -> the 32 (f32) MFMAs of step it.
-    // So the matrix pipe never waits for LDS (a step's fragments are requested one whole MFMA phase before their use) and a
-    // global load has TWO phases to land (one was not enough: activations the previous launch has just written come from
-    // another XCD's L2 / the Infinity Cache, > 1000 cycles under load); one wave per SIMD keeps its pipe busy without a
-    // partner.  The body is unconditional: past the last step the loads repeat the last step's addresses and nobody reads
-    // what they bring (four redundant 64-byte loads per thread against a branch-free loop).
-    u32x4 ra0[2], rb0[2], ra1[2], rb1[2];                 // two staging sets: one K step of this thread's 2 + 2 tile-row chunks each
-    // address of the zero page, pinned in a VGPR pair: rematerialised inside the loop it is a scalar load per step whose
-    // lgkmcnt(0) wait also drains the fragment reads just issued
-    unsigned long long z = (unsigned long long)reinterpret_cast<size_t>(g_zero16);
-    asm volatile("" : "+v"(z));
-    auto gload = [&](u32x4 (&ra)[2], u32x4 (&rb)[2]) __attribute__((always_inline)) {
-        const int e = c0 + chunk * EPC;
-        const size_t koff = (size_t)tap * p.c_pad + c0;
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa) ra[pa] = *reinterpret_cast<const u32x4*>(wbase + pa * wpass + koff);
-        // invalid rows (no such output pixel) and the K tail read the 16 zero bytes of g_zero16.  The select is done with a
-        // mask on the address difference, not "ok ? a : z": the compiler turned that into a divergent branch on the K-tail
-        // test whose join waits for vmcnt(0) - the weight loads just issued - in front of every step's MFMAs
-        const int ktail = (e - src_cin) >> 31;            // all ones while e < src_cin
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            const long long mask = (long long)(ktail & ~(roff[pb] >> 31));
-            const unsigned long long a = (unsigned long long)reinterpret_cast<size_t>(src + (size_t)(roff[pb] & 0x7fffffff) + e);
-            // (an explicit global-address-space pointer: from a plain integer the compiler makes a FLAT load, which also
-            // counts in lgkmcnt - the next barrier's LDS drain would then wait for it)
-            typedef const u32x4 __attribute__((address_space(1)))* gptr_t;
-            rb[pb] = *reinterpret_cast<gptr_t>(z + ((a - z) & (unsigned long long)mask));
-        }
+    // Pipeline.  Iteration `it`, every wave: barrier -> [waves 4-7: the MFMAs of step it-1 on the fragments fetched in the
+    // previous iteration] -> read the fragments of step `it` (LDS buffer it & 1, stored in the previous iteration) -> store
+    // the staged global data of step it+1 (staging set (it+1) & 1) into buffer (it+1) & 1 (every wave's reads of that buffer
+    // completed before the barrier: __syncthreads drains lgkmcnt, not vmcnt) -> request step it+3 from global memory into the
+    // staging set just freed -> [waves 0-3: the MFMAs of step `it`].  A global load has two steps to land (activations the
+    // previous launch has just written come from another XCD's L2 / the Infinity Cache) - see the staging sets below for
+    // how far ahead the requests really run.  The body is unconditional: past the last step the loads repeat the last
+    // step's addresses and nobody reads what they bring.
+    // FOUR staging sets (this thread's weight chunk + activation chunk of a step each): what bounds this kernel at one
+    // workgroup per CU is bytes in flight / latency - a step moves 16 KB into the CU and a load that misses the XCD's L2
+    // (activations the previous launch wrote on another XCD, weights on their first touch) takes ~0.7 us, so two sets
+    // (32 KB in flight) give 0.36 us per step for the loads ALONE and, interleaved with the MFMA phases, 0.72 us per step
+    // against 0.43 of MFMA time (tools/exp_small.sh, tools/exp_small_stamps.sh)
+    u32x4 sa0, sb0, sa1, sb1, sa2, sb2, sa3, sb3;
+    int sm0 = 0, sm1 = 0, sm2 = 0, sm3 = 0;               // ... and whether the activation chunk is real (all ones) or must read as zero
+    // The two global loads of a step: "saddr + 32-bit voffset" form, issued from inline asm.  The per-step part of both
+    // addresses is wave-uniform (tile's weight rows + tap / channel offset; tensor + channel offset) and lives in SGPRs, the
+    // per-thread part changes only with the tap - a step costs scalar adds and two VMEM issues instead of ~20 VALU of 64-bit
+    // address arithmetic (tools/exp_small_stamps.sh: 440-670 of a step's ~1600 cycles sat there).  An invalid row (no such
+    // output pixel) and the K tail load from a clamped in-bounds address and are zeroed after they land (staged()).
+    // The loads are waited for by hand (s_waitcnt vmcnt(6): the six loads of the OTHER three staging sets stay in flight);
+    // with compiler-visible loads the waitcnt pass, merging the loop's entry and back edges, drained them a step early.
+    auto gload = [&](u32x4& sa, u32x4& sb, int& sm) __attribute__((always_inline)) {
+        const T* wsb = wtile + (size_t)tap * p.c_pad + c0;                      // uniform
+        const T* asb = src + c0;                                                 // uniform
+        sm = ((c0 + chunk * EPC - src_cin) >> 31) & ~(roff >> 31);               // all ones: a real chunk
+        const unsigned av = avoff & (unsigned)sm;
+        asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %4, %5"
+                     : "=&v"(sa), "=&v"(sb) : "v"(wvoff), "s"(wsb), "v"(av), "s"(asb) : "memory");
     };
-    auto lds_store = [&](int buf, const u32x4 (&ra)[2], const u32x4 (&rb)[2]) __attribute__((always_inline)) {
+    auto staged = [&](u32x4& sa, u32x4& sb, int sm) __attribute__((always_inline)) {     // this set has landed (the other may be in flight)
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(sa), "+v"(sb) :: "memory");
+        sb.x &= (unsigned)sm; sb.y &= (unsigned)sm; sb.z &= (unsigned)sm; sb.w &= (unsigned)sm;
+    };
+    auto lds_store = [&](int buf, const u32x4& sa, const u32x4& sb) __attribute__((always_inline)) {
         unsigned char* As = lds + buf * STAGE;
-        unsigned char* Bs = As + BN * 128;
-#pragma unroll
-        for (int pa = 0; pa < 2; ++pa) *reinterpret_cast<u32x4*>(As + lds_swz(row0 + 32 * pa, chunk)) = ra[pa];
-#pragma unroll
-        for (int pb = 0; pb < 2; ++pb) *reinterpret_cast<u32x4*>(Bs + lds_swz(row0 + 32 * pb, chunk)) = rb[pb];
+        *reinterpret_cast<u32x4*>(As + lds_swz(row0, chunk)) = sa;
+        *reinterpret_cast<u32x4*>(As + BN * 128 + lds_swz(row0, chunk)) = sb;
     };
     const int nloc = s_end - s_begin;
     int issued = 0;                                       // K steps requested so far
-    auto next_gload = [&](u32x4 (&ra)[2], u32x4 (&rb)[2]) __attribute__((always_inline)) {
+    auto next_gload = [&](u32x4& sa, u32x4& sb, int& sm) __attribute__((always_inline)) {
         if (issued > 0 && issued < nloc) {                // (uniform) move on to the next step; past the end: repeat the last
             c0 += BK;
             if (c0 >= src_cpad) {
@@ -196,24 +201,19 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
             }
         }
         ++issued;
-        gload(ra, rb);
-        // keep the requests HERE, in front of the step's MFMAs: left alone the scheduler sinks them past the MFMAs to just
-        // before the barrier, where the LDS store right behind it waits out their whole latency every step
+        gload(sa, sb, sm);
+        // keep the requests HERE, in front of the MFMAs: left alone the scheduler sinks them to just before the next
+        // barrier, where the LDS store right behind it waits out their whole latency every step
         __builtin_amdgcn_sched_barrier(0);
     };
-    const int lrow = lane & 15, lchunk = lane >> 4;
-    auto frag_load = [&](int buf, u32x4 (&a)[2][2], u32x4 (&b)[2][2]) __attribute__((always_inline)) {
+    const int lrow = lane & 15, lchunk = half * 4 + (lane >> 4);        // this wave's 64-byte half of the step
+    auto frag_load = [&](int buf, u32x4 (&a)[2], u32x4 (&b)[2]) __attribute__((always_inline)) {
         const unsigned char* As = lds + buf * STAGE;
         const unsigned char* Bs = As + BN * 128;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 32 + i * 16 + lrow, lchunk));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[kk][i] = *reinterpret_cast<const u32x4*>(As + lds_swz(wn * 32 + i * 16 + lrow, kk * 4 + lchunk));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                b[kk][j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * 32 + j * 16 + lrow, kk * 4 + lchunk));
-        }
+        for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const u32x4*>(Bs + lds_swz(wm * 32 + j * 16 + lrow, lchunk));
     };
 
     f32x4 acc[2][2];
@@ -223,34 +223,63 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(const ConvK p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (nloc > 0) {
-        u32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];
+        u32x4 fa[2], fb[2];
         set_tap(tap);
-        next_gload(ra0, rb0);                            // step 0
-        next_gload(ra1, rb1);                            // step 1
-        lds_store(0, ra0, rb0);
-        next_gload(ra0, rb0);                            // step 2
-        __syncthreads();
-        frag_load(0, fa0, fb0);
-        lds_store(1, ra1, rb1);
-        next_gload(ra1, rb1);                            // step 3
-        for (int it = 0; it < nloc; it += 2) {
-            // even step: its fragments are in set 0; buffer 1 holds step it+1, staging set 0 step it+2, set 1 (in flight) it+3
-            __syncthreads();
-            frag_load(1, fa1, fb1);
-            lds_store(0, ra0, rb0);
-            next_gload(ra0, rb0);                        // step it+4
-            mma_step<T>(acc, fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it + 1 >= nloc) break;
-            // odd step
-            __syncthreads();
-            frag_load(0, fa0, fb0);
-            lds_store(1, ra1, rb1);
-            next_gload(ra1, rb1);                        // step it+5
-            mma_step<T>(acc, fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
+        next_gload(sa0, sb0, sm0);                       // step 0
+        next_gload(sa1, sb1, sm1);                       // step 1
+        next_gload(sa2, sb2, sm2);                       // step 2
+        next_gload(sa3, sb3, sm3);                       // step 3
+        staged(sa0, sb0, sm0);
+        lds_store(0, sa0, sb0);
+        next_gload(sa0, sb0, sm0);                       // step 4
+        // one K step: LDS buffer `it & 1` holds it; staging set (it + 1) & 3 holds step it+1, the other three are in flight
+#define CP360_SMALL_STEP(IT, BUF, SA, SB, SM)                                                        \
+        {                                                                                            \
+            __syncthreads();                                                                         \
+            if (half && (IT) > 0) mma_half<T>(acc, fa, fb);          /* trailing waves: step IT-1 */ \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
+            frag_load(BUF, fa, fb);                                                                  \
+            staged(SA, SB, SM);                                                                      \
+            lds_store((BUF) ^ 1, SA, SB);                                                            \
+            next_gload(SA, SB, SM);                                  /* step IT+5 */                 \
+            if (!half) mma_half<T>(acc, fa, fb);                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                       \
         }
+        for (int it = 0; it < nloc; it += 4) {
+            CP360_SMALL_STEP(it, 0, sa1, sb1, sm1);
+            if (it + 1 >= nloc) break;
+            CP360_SMALL_STEP(it + 1, 1, sa2, sb2, sm2);
+            if (it + 2 >= nloc) break;
+            CP360_SMALL_STEP(it + 2, 0, sa3, sb3, sm3);
+            if (it + 3 >= nloc) break;
+            CP360_SMALL_STEP(it + 3, 1, sa0, sb0, sm0);
+        }
+#undef CP360_SMALL_STEP
+        if (half) mma_half<T>(acc, fa, fb);                         // trailing waves: the last step
+        // the redundant loads past the last step are still in flight: their registers must not be reused before they land
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sa0), "+v"(sb0), "+v"(sa1), "+v"(sb1), "+v"(sa2), "+v"(sb2), "+v"(sa3), "+v"(sb3) :: "memory");
     }
+
+    // ---- the trailing waves hand their sums over through LDS (the pipeline buffers are free): [pair][register][lane]
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(lds);
+    const int pair = wave & 3;
+    if (half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xch[((pair * 16) + (i * 2 + j) * 4 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (half) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] += xch[((pair * 16) + (i * 2 + j) * 4 + e) * 64 + lane];
 
     // ---- epilogue: a lane owns channels n .. n+7 of pixel m for each of its two pixel blocks
     const int ml = lane & 15;
@@ -328,7 +357,7 @@ void cp360_launch_conv_small(ConvK& k, int dtype, hipStream_t st) {
     // share whichever operand panel is larger through the XCD's L2
     k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
     dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
-    if (dtype == CP360_F32) hipLaunchKernelGGL((conv_small_kernel<float>), grid, dim3(256), 0, st, k);
-    else if (dtype == CP360_F16) hipLaunchKernelGGL((conv_small_kernel<f16_raw>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((conv_small_kernel<bf16_raw>), grid, dim3(256), 0, st, k);
+    if (dtype == CP360_F32) hipLaunchKernelGGL((conv_small_kernel<float>), grid, dim3(512), 0, st, k);
+    else if (dtype == CP360_F16) hipLaunchKernelGGL((conv_small_kernel<f16_raw>), grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((conv_small_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
 }

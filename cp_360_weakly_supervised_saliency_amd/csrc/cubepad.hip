@@ -637,7 +637,7 @@ __global__ __launch_bounds__(1024) void cubepad_nchw_lds6_kernel(const unsigned 
     typedef typename ElemOf<ES>::T T;
     constexpr int E = 16 / ES;
     constexpr int LOG_E = E == 16 ? 4 : (E == 8 ? 3 : (E == 4 ? 2 : 1));
-    constexpr int UNR = 4;
+    constexpr int UNR = ES == 1 ? 2 : 4;          // (byte elements: 16 element moves per chunk - two chunks in flight fit the 128 VGPRs of a 1024-thread workgroup without spilling)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
     const int n = g.n, Hp = n + g.pt + g.pd, Wp = n + g.pl + g.pr, LR = g.pl + g.pr;
     const int tid = threadIdx.x, NT = blockDim.x;

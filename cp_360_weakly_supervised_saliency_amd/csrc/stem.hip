@@ -302,7 +302,9 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const T* __restrict__ xp
         // stem row 8 band + w = patch rows 2 (w + 1) ..; the halo row = patch rows 0 ..
         const unsigned char* P = pbuf + (2 * (wave + 1)) * ROW_BYTES + 16 * (lrow + lchunk);
         const unsigned char* PH = pbuf + 16 * (wave * 16 + lrow + lchunk);
-#pragma unroll
+        // (not unrolled: with the seven filter rows unrolled the next row's 12 fragment reads are hoisted above this row's
+        // MFMAs, 256 VGPRs + 2 spilled; rolled: 204, no scratch, the same time - 4.98 against 4.99 ms per 64-frame stage)
+#pragma unroll 1
         for (int ky = 0; ky < 7; ++ky) {
             u32x4 a[4], b[8];
 #pragma unroll

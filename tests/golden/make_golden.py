@@ -78,6 +78,9 @@ def import_reference():
 CUBEPAD_SMALL = [(4, 1), (5, 2), (7, 1), (8, 3), (6, [1, 2, 3, 1]), (5, [0, 2, 1, 0]),
                  (5, [2, 0, 0, 3]), (6, [3, 1, 1, 2]), (4, [0, 0, 1, 1]), (4, [1, 1, 0, 0])]
 CUBEPAD_HASHED = [(224, 3, 3), (56, 1, 64), (112, 1, 8), (14, 1, 32), (9, 2, 5)]   # (n, p, C): sha only
+# the reference's own smoke test (model/cube_pad.py:256-261): CubePad(2) on [12, 64, 256, 256] -> [12, 64, 260, 260]; seeded
+# values instead of its zeros so that the hash pins every element
+CUBEPAD_SMOKE = (256, 2, 64, 2)                                                        # (n, p, C, cubes)
 
 
 def cubepad_input(n, C, groups, seed):
@@ -102,6 +105,10 @@ def gen_cubepad(R, out):
         m = R['cpu_pads'](R['cp'].CubePad(p, use_gpu=False))
         y = m(torch.from_numpy(x)).numpy()
         hashed['%d_%d_%d' % (n, p, C)] = sha(y)
+    n, p, C, groups = CUBEPAD_SMOKE
+    y = R['cpu_pads'](R['cp'].CubePad(p, use_gpu=False))(torch.from_numpy(cubepad_input(n, C, groups, 2100))).numpy()
+    assert y.shape == (6 * groups, C, n + 2 * p, n + 2 * p)
+    hashed['smoke_%d_%d_%d_x%d' % CUBEPAD_SMOKE] = sha(y)
     import json
     json.dump(hashed, open(os.path.join(out, 'cubepad_sha256.json'), 'w'), indent=1, sort_keys=True)
     print('cubepad fixtures written')

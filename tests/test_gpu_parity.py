@@ -58,6 +58,21 @@ def test_cubepad_golden_hashed_bit_exact(golden_dir):
         assert sha(got) == want['%d_%d_%d' % (n, p, C)], (n, p, C)
 
 
+def test_cubepad_reference_smoke(golden_dir):
+    """The reference's own smoke test as a GPU test (model/cube_pad.py:256-261: ``CubePad(2)`` on a [12, 64, 256, 256] CUDA
+    tensor, printing the output size [12, 64, 260, 260]) - through the drop-in module, against the hash of the reference's
+    output for the same seeded input, and as the reference runs it (zeros in, size out)."""
+    want = json.load(open(os.path.join(golden_dir, 'cubepad_sha256.json')))
+    n, p, C, groups = mg.CUBEPAD_SMOKE
+    cp = CubePad(p)
+    got = cp(torch.from_numpy(mg.cubepad_input(n, C, groups, 2100)).to(DEV))
+    assert tuple(got.size()) == (12, 64, 260, 260)
+    assert sha(got.cpu().numpy()) == want['smoke_%d_%d_%d_x%d' % mg.CUBEPAD_SMOKE]
+    aa = torch.FloatTensor(np.zeros([12, 64, 256, 256])).to(DEV)
+    out = cp(aa)
+    assert tuple(out.size()) == (12, 64, 260, 260) and not bool(out.any())
+
+
 @pytest.mark.parametrize('dtype', [torch.uint8, torch.bfloat16, torch.float32, torch.float64])
 def test_cubepad_every_element_size(dtype):
     x = hashrng.integers(77, (12, 5, 9, 9), 0, 200).astype(np.float64)

@@ -34,6 +34,16 @@ def test_cubepad_hashed_bit_exact(golden_dir):
         assert sha(o_cubepad.cubepad(x, p)) == want['%d_%d_%d' % (n, p, C)]
 
 
+def test_cubepad_reference_smoke_shape_and_hash(golden_dir):
+    """The reference's only executable test (model/cube_pad.py:256-261): CubePad(2) on [12, 64, 256, 256] -> [12, 64, 260, 260]
+    (seeded values instead of its zeros; hash of the reference's own output)."""
+    want = json.load(open(os.path.join(golden_dir, 'cubepad_sha256.json')))
+    n, p, C, groups = mg.CUBEPAD_SMOKE
+    got = o_cubepad.cubepad(mg.cubepad_input(n, C, groups, 2100), p)
+    assert got.shape == (12, 64, 260, 260)
+    assert sha(got) == want['smoke_%d_%d_%d_x%d' % mg.CUBEPAD_SMOKE]
+
+
 def test_cubepad_rejects_bad_batch():
     with pytest.raises(ValueError):
         o_cubepad.cubepad(np.zeros((5, 1, 4, 4), np.float32), 1)

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Timing ablations of conv_small_kernel (local build, run on the GPU box with CP360_LIB=...): which part of a K step costs what.
+#   tools/exp_small.sh  -> tools/_exp/libcp360_small_{nomma,noglobal,nobar}.so   (most variants compute garbage)
+set -e
+R=$(cd $(dirname $0)/.. && pwd)
+mkdir -p $R/tools/_exp
+for V in nomma noglobal nolds; do
+  D=/tmp/exp_small_$V
+  rm -rf $D && mkdir -p $D && cp -r $R/cp_360_weakly_supervised_saliency_amd/csrc $D/ && cd $D/csrc && rm -f conv_small.o libcp360.so
+  sed -i 's#"../../include/cp360.h"#"'$R'/include/cp360.h"#' common.h
+  python3 - "$V" <<'PY'
+import sys
+v = sys.argv[1]
+s = open('conv_small.hip').read()
+def sub(a, b):
+    global s
+    assert a in s, a
+    s = s.replace(a, b)
+if v == 'nomma':      # no MFMAs: the fragments are consumed by an empty asm
+    sub('                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]), acc[i][j], 0, 0, 0);',
+        '                    asm volatile("" :: "v"(a[i][e]), "v"(b[j][e]));')
+if v == 'noglobal':   # every global load hits the zero page
+    sub('sa = *reinterpret_cast<const u32x4*>(wrow + (size_t)tap * p.c_pad + c0);', 'sa = *reinterpret_cast<const u32x4*>(g_zero16);')
+    sub('const long long mask = (long long)(((e - src_cin) >> 31) & ~(roff >> 31));', 'const long long mask = 0;')
+if v == 'nolds':      # fragments are not re-read from LDS (stores and barriers stay)
+    sub('            frag_load(0, fa, fb);\n            lds_store(1, sa1, sb1);', '            if (it == 0) frag_load(0, fa, fb);\n            lds_store(1, sa1, sb1);')
+    sub('            frag_load(1, fa, fb);\n            lds_store(0, sa0, sb0);', '            lds_store(0, sa0, sb0);')
+open('conv_small.hip', 'w').write(s)
+PY
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c conv_small.hip -o conv_small.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/_exp/libcp360_small_$V.so *.o
+  echo built $V
+done
