@@ -374,6 +374,44 @@ def level1_bench(dev, precision='fp32', reps=5):
                     'to_equi_nn + torch.max per window; PCIe copies and NCHW<->NHWC conversions of every call included'}
 
 
+def sliding_bench(dev, precision='bf16', n_frames=64, seq_len=5, reps=5):
+    """The reference's temporal workload as it runs it (temporal_model/test_temporal.py:57-62, config.yaml:34): a stride-1
+    sliding window of seq_len 5 over ONE video's cube_feat sequence - every window is its own min / max normalisation,
+    hidden = cell = first frame and 5 ConvLSTM steps, so a video of n frames costs 5 (n - 5) cell updates.  Here all windows of a
+    64-frame video run in lock step (ClipRunner.run(sliding=True): 60 windows over 64 frames, zero-copy over one feature
+    sequence, GEMM M = 60 * 294) on CAM features resident in HBM; the static stage is not part of this line."""
+    from cp_360_weakly_supervised_saliency_amd.model.clstm import ConvLSTMCell
+    from cp_360_weakly_supervised_saliency_amd.temporal_model.test_temporal import ClipRunner
+    from cp_360_weakly_supervised_saliency_amd.utils.cube_to_equi import Cube2Equi
+    cs = synth.clstm_state(seed=2)
+    cell = ConvLSTMCell(1000, 1000, precision=precision)
+    cell.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in cs.items()})
+    cell = cell.to(dev).eval()
+    n_win = n_frames - seq_len + 1
+    feats = synth.cam_clip(7001, n_frames)                                   # [n, 6, 1000, 7, 7]
+    cam = torch.from_numpy(np.ascontiguousarray(feats.transpose(0, 1, 3, 4, 2)).reshape(n_frames, 294, 1000)).to(dev)
+    runner = ClipRunner(cell, Cube2Equi(7, device=dev), n_win, seq_len)
+    with torch.no_grad():
+        runner.run(cam, sliding=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            maps = runner.run(cam, sliding=True)
+        torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert tuple(maps.shape) == (n_win, 14, 28) and bool(torch.isfinite(maps).all())
+    st = cell.__dict__.get('_stage')
+    if st is not None:
+        st.close()
+    del cell, runner
+    torch.cuda.empty_cache()
+    return {'name': 'reference temporal workload: stride-1 sliding window, seq_len 5, one 64-frame video, %s' % precision,
+            'maps_per_s': round(n_win / dt, 1), 'ms_per_video': round(1000 * dt, 3), 'windows': n_win, 'cell_updates': n_win * seq_len,
+            'cell_updates_per_s': round(n_win * seq_len / dt, 1), 'dtype': DTYPE[precision],
+            'what': 'ClipRunner.run(sliding=True): %d windows x %d steps in lock step over one resident cube_feat sequence '
+                    '(test_temporal.py:57-62); temporal stage only' % (n_win, seq_len)}
+
+
 def cpu_baseline(precision, dev, static_precision=None):
     """the oracle (numpy / torch-CPU restatement of the reference, oracle/) on the host
     cores, timed on config C1 (one 960x1920 frame, static stage) and on ONE 16-frame 1024x2048 clip end to
@@ -561,6 +599,7 @@ def main():
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
             add('C4 per-GPU shard, return_all_steps: a map after every ConvLSTM step ([4, 16, 14, 28])',
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, all_steps=True)
+            sec.append(sliding_bench(dev))
             sec.append(level1_bench(dev))
             line['secondary'] = sec
         if world == 1 and not args.no_cpu_baseline and not args.stub_engine:

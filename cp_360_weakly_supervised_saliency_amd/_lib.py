@@ -28,28 +28,35 @@ OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
 ABI_VERSION = 304
 
-# every exported symbol of include/cp360.h (checked by tests/test_abi.py)
-SYMBOLS = [
+
+# every exported symbol of include/cp360.h - the documented boundary (checked by tests/test_abi.py)
+PUBLIC_SYMBOLS = [
     'cp360_strerror', 'cp360_version', 'cp360_conv_desc_bytes', 'cp360_cubepad_table_host', 'cp360_cubepad_nchw',
-    'cp360_cubepad_nhwc', 'cp360_nchw_to_nhwc', 'cp360_nhwc_to_nchw', 'cp360_equi2cube',
-    'cp360_cube2equi', 'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits',
-    'cp360_conv_pack_weights', 'cp360_conv_pack_weights2', 'cp360_conv_forward', 'cp360_conv_forward2',
-    'cp360_conv_finish',
+    'cp360_cubepad_nhwc', 'cp360_nchw_to_nhwc', 'cp360_nhwc_to_nchw', 'cp360_equi2cube', 'cp360_cube2equi',
+    'cp360_conv_packed_bytes', 'cp360_conv_partial_bytes', 'cp360_conv_suggest_splits', 'cp360_conv_pack_weights',
+    'cp360_conv_pack_weights2', 'cp360_conv_forward', 'cp360_conv_forward2', 'cp360_conv_finish',
     'cp360_cubepad_maxpool3s2', 'cp360_lstm_gates', 'cp360_lstm_gates_next', 'cp360_window_minmax',
-    'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8', 'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes', 'cp360_band3x3_pack_weights', 'cp360_band3x3_forward',
-    'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1', 'cp360_l1block_forward', 'cp360_l1block_forward_wide', 'cp360_l1block_conv2_bytes',
-    'cp360_l1block_pack_conv2',
-    'cp360_l2block_packed_bytes', 'cp360_l2block_pack_weights', 'cp360_l2block_forward', 'cp360_l2block_forward_next', 'cp360_set_launch_order', 'cp360_stem_pool_border_bytes', 'cp360_stem_pool_forward',
-    'cp360_l3block_packed_bytes', 'cp360_l3block_pack_weights', 'cp360_l3block_forward',
+    'cp360_window_normalize', 'cp360_resize_ksize', 'cp360_resize_coeffs_host', 'cp360_resize_lanczos_u8',
     'cp360_resize_linear_f32', 'cp360_metric_work_bytes', 'cp360_metric_auc_prepare', 'cp360_metric_auc_judd',
-    'cp360_metric_auc_borji', 'cp360_metric_cc_sim',
-    'cp360_resize_ksize2', 'cp360_resize_coeffs_host2', 'cp360_overlay_colorize', 'cp360_overlay_blend_u8',
-    'cp360_l2first_w3d_bytes', 'cp360_l2first_pack_w3d', 'cp360_l2first_forward',
-    'cp360_fold_bn', 'cp360_create', 'cp360_destroy', 'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward',
-    'cp360_clstm_load', 'cp360_clstm_workspace_bytes', 'cp360_clstm_step',
-    'cp360_conv_finish_add', 'cp360_window_normalize_frames', 'cp360_clstm_window_workspace_bytes', 'cp360_clstm_window',
-    'cp360_clock_probe', 'cp360_conv_prefer_clip',
+    'cp360_metric_auc_borji', 'cp360_metric_cc_sim', 'cp360_resize_ksize2', 'cp360_resize_coeffs_host2',
+    'cp360_overlay_colorize', 'cp360_overlay_blend_u8', 'cp360_fold_bn', 'cp360_create', 'cp360_destroy',
+    'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward', 'cp360_clstm_load', 'cp360_clstm_workspace_bytes',
+    'cp360_clstm_step', 'cp360_conv_finish_add', 'cp360_window_normalize_frames',
+    'cp360_clstm_window_workspace_bytes', 'cp360_clstm_window', 'cp360_clock_probe', 'cp360_conv_prefer_clip',
+    'cp360_conv_plan_describe', 'cp360_resnet_plan_describe',
 ]
+# ... and of include/cp360_internal.h: the shape-specific fused kernels the stage contexts are built from (exported for
+# tests and the CP360_CTX=0 planner; not part of the boundary)
+INTERNAL_SYMBOLS = [
+    'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes',
+    'cp360_band3x3_pack_weights', 'cp360_band3x3_forward', 'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1',
+    'cp360_l1block_forward', 'cp360_l1block_forward_wide', 'cp360_l1block_conv2_bytes', 'cp360_l1block_pack_conv2',
+    'cp360_l2block_packed_bytes', 'cp360_l2block_pack_weights', 'cp360_l2block_forward',
+    'cp360_l2block_forward_next', 'cp360_set_launch_order', 'cp360_stem_pool_border_bytes',
+    'cp360_stem_pool_forward', 'cp360_l3block_packed_bytes', 'cp360_l3block_pack_weights', 'cp360_l3block_forward',
+    'cp360_l2first_w3d_bytes', 'cp360_l2first_pack_w3d', 'cp360_l2first_forward',
+]
+SYMBOLS = PUBLIC_SYMBOLS + INTERNAL_SYMBOLS
 
 
 class ConvDesc(C.Structure):
@@ -176,6 +183,8 @@ def lib():
     L.cp360_clstm_window.argtypes = [vp, vp, sz, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.cp360_clock_probe.argtypes = [vp, i, i, vp]
     L.cp360_conv_prefer_clip.argtypes = [pd]
+    L.cp360_conv_plan_describe.argtypes = [pd, C.c_char_p, sz]
+    L.cp360_resnet_plan_describe.argtypes = [vp, i, i, C.c_char_p, sz]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):

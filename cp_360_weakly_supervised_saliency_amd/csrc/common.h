@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
-#include "../../include/cp360.h"
+#include "../../include/cp360_internal.h"
 
 #define CP360_CHECK_HIP()                                        \
     do {                                                         \

@@ -35,6 +35,7 @@
 //   bf16 path: v_mfma_f32_16x16x32_bf16 (a lane's 16-byte chunk = its 8 k-values).
 //   Split-K (gridDim.z) writes f32 partial slabs; conv_finish / lstm_gates reduce them.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -1761,6 +1762,40 @@ extern "C" int cp360_conv_prefer_clip(const cp360_conv_desc* d) {
     t.clip_resident = 0;
     if (check_desc(&t) || !small_eligible(&t)) return 1;
     return plan_big(&c).cost <= plan_small(&t).cost ? 1 : 0;
+}
+
+extern "C" int cp360_conv_plan_describe(const cp360_conv_desc* d, char* buf, size_t cap) {
+    if (!d || !buf || cap == 0) return CP360_ERR_NULL;
+    cp360_conv_desc t = *d;
+    t.splits = 1;
+    int rc = check_desc(&t);
+    if (rc) return rc;
+    const ConvPlan pl = plan_of(&t);
+    int bn = 0, bm = 0, slots = 0;
+    tile_of(&t, &bn, &bm, &slots);
+    const long long M = (long long)t.n_img * t.h_out * t.w_out;
+    const char* name;
+    long long wgs;
+    if (t.clip_resident) {
+        const bool face = t.h_in == 16;
+        name = face ? "conv_clip 256 ch x one 16x16 face (activations LDS-resident)" : "conv_clip 256 ch x one cube (activations LDS-resident)";
+        wgs = (long long)((t.c_out + 255) / 256) * (face ? t.n_img : t.n_img / 6);
+    } else if (bm == 64) {
+        name = "conv_small 64 ch x 64 px (8 waves)";
+        wgs = (long long)((t.c_out + 63) / 64) * ((M + 63) / 64);
+    } else if (t.c_out < 256 || bn != 256) {
+        const bool narrow = t.c_out <= 64;
+        name = narrow ? "conv_igemm 64 ch x 256 px (4 waves)" : "conv_igemm 128 ch x 128 px (4 waves)";
+        wgs = narrow ? (long long)((t.c_out + 63) / 64) * ((M + 255) / 256) : (long long)((t.c_out + 127) / 128) * ((M + 127) / 128);
+    } else {
+        const int px = bm == 129 ? 128 : bm;
+        name = bm == 129 ? "conv_igemm_ring2 256 ch x 128 px (two workgroups per CU)"
+               : bm == 304 ? "conv_igemm_ring 256 ch x 304 px" : bm >= 256 ? "conv_igemm_ring 256 ch x 256 px" : "conv_igemm_dma 256 ch x 128 px";
+        wgs = (long long)((t.c_out + 255) / 256) * ((M + px - 1) / px);
+    }
+    const int n = snprintf(buf, cap, "%s, %lld workgroups x split-K %d%s, model %.0f us", name, wgs * pl.splits, pl.splits,
+                           t.c_in2 > 0 ? " (+ second source)" : "", pl.cost);
+    return n < 0 ? CP360_ERR_BAD_SHAPE : (n >= (int)cap ? (int)cap - 1 : n);
 }
 
 static int pack_weights_impl(const cp360_conv_desc* d, const float* w_oihw, const float* scale, const float* w2,

@@ -12,7 +12,10 @@
 // with exactly the descriptors the Python planning produces, so both paths give the same bits (tests/test_ctx.py).
 #include "common.h"
 #include <new>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <string>
 #include <vector>
 
 namespace {
@@ -156,6 +159,11 @@ struct Run {
     int dtype = 0;
 
     const float* finish_extra = nullptr;         // one more f32 addend for the NEXT split-K finish (consumed by it)
+    std::string* desc = nullptr;                 // dry runs: one line per planned launch (cp360_resnet_plan_describe)
+    const char* where = "";
+    void note(const char* text) {
+        if (desc) { *desc += text; *desc += "\n"; }
+    }
 
     int conv(const CConv& c, const void* in, int n_img, int h, int w, const void* residual, int ld_res, void* out,
              int ld_out, int out_coff, const void* x2, int h2, int w2, int ps2, bool raw, bool raw_slab_rows,
@@ -179,7 +187,18 @@ struct Run {
             if (need > partial_need) partial_need = need;
             if (!dry && need > partial_cap) return CP360_ERR_BAD_SHAPE;
         }
-        if (dry) return CP360_OK;
+        if (dry) {
+            if (desc) {
+                char plan[200], line[320];
+                cp360_conv_desc dd = d;
+                dd.splits = 1;
+                if (cp360_conv_plan_describe(&dd, plan, sizeof(plan)) < 0) plan[0] = 0;
+                snprintf(line, sizeof(line), "  %s conv %dx%d %d -> %d @ %dx%d%s: %s%s", where, c.kh_w, c.kw_w, c.c_in_w, c.c_out, h, w,
+                         c.stride > 1 ? " stride 2" : "", plan, force_splits > 0 ? " (split count fixed by the caller)" : "");
+                note(line);
+            }
+            return CP360_OK;
+        }
         const void* pk = cr ? c.packed_clip : c.packed;
         if (!pk) return CP360_ERR_UNSUPPORTED;
         if (to_partial) {
@@ -430,7 +449,7 @@ struct ResnetWs {
 
 // The static stage as a launch sequence (or, dry, its workspace needs).  faces_p3: [n_img, cd+6, cd+6, 4] NHWC4.
 int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd, float* cam_out, void* feat_out,
-               unsigned char* ws, size_t ws_bytes, hipStream_t st, ResnetWs* need) {
+               unsigned char* ws, size_t ws_bytes, hipStream_t st, ResnetWs* need, std::string* desc = nullptr) {
     CResnet& R = ctx->rn;
     if (!R.loaded) return CP360_ERR_NULL;
     if (n_img <= 0 || cd < 32 || cd % 32 != 0) return CP360_ERR_BAD_SHAPE;
@@ -444,6 +463,7 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
     run.dry = dry;
     run.st = st;
     run.dtype = dtype;
+    run.desc = dry ? desc : nullptr;
     unsigned char* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned char* border = nullptr;
     if (!dry) {
@@ -473,9 +493,16 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
             CK(cp360_cubepad_maxpool3s2(other(1), buf[cur], n_img, cd / 2, 64, dtype, st));
         }
     } else if (!(h16 && (cd == 224 || cd == 512))) {
+        run.note("stem: generic convolution (7 taps of 8 pixels x 4 channels) + cubepad_maxpool kernel");
+        run.where = "stem";
         CK(run.conv(R.stem, nullptr, n_img, cd + 6, cd + 6, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr));
+    } else {
+        run.note(cd == 224 ? "stem: FUSED stem + CubePad(1) + max-pool, one launch (K3a+K3b, cube 224, 16-bit)"
+                           : "stem: resident-patch stem kernel (K3a, cube 512, 16-bit) + cubepad_maxpool kernel");
     }
     // per-convolution Bottleneck (Bottleneck.forward_nhwc): x = buf[cur] -> buf[cur] (rotated); mid0: conv1 already done
+    char wherebuf[32];
+    auto at = [&](int layer, int block) { snprintf(wherebuf, sizeof(wherebuf), "layer%d.%d", layer, block); run.where = wherebuf; };
     auto bottleneck = [&](CBlock& B, int hin, const void* mid0) -> int {
         const int hout = (hin + 2 - 3) / B.stride + 1;
         const void* mid = mid0;
@@ -500,6 +527,8 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
     {
         std::vector<CBlock>& Lr = R.layer[0];
         if (h16 && (face == 56 || face == 128)) {
+            run.note("layer1: conv1 of block 0, then ONE fused launch per Bottleneck (K3d: conv2 + conv3 + residual / downsample + the next conv1)");
+            at(1, 0);
             // conv1 of the first block, then ONE launch per Bottleneck (K3d); the chained conv1 output ping-pongs
             CK(run.conv(Lr[0].c1, buf[cur], n_img, face, face, nullptr, 0, other(1), 0, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr));
             if (!dry) {
@@ -531,14 +560,17 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
                 mid2 = (const void*)1;                   // dry: only "conv1 is not run"
             }
         } else {
-            for (CBlock& B : Lr) CK(bottleneck(B, face, nullptr));
+            run.note("layer1: GENERIC path, one launch per convolution (the fused tail kernels need a 16-bit type and 56x56 / 128x128 faces)");
+            for (size_t b = 0; b < Lr.size(); ++b) { at(1, (int)b); CK(bottleneck(Lr[b], face, nullptr)); }
         }
     }
     // ---- layer2 / layer3: first block per convolution, identity blocks as fused tails where the kernels exist
     bool l2_mid1 = false;                                 // layer2.0's kernel also computed layer2.1's conv1
     for (int L = 1; L <= 2; ++L) {
         std::vector<CBlock>& Lr = R.layer[L];
+        at(L + 1, 0);
         if (L == 1 && h16 && face == 56) {
+            run.note("layer2.0: ONE fused launch after its conv1 (K3f: stride-2 conv2 + conv3 + downsample + layer2.1's conv1)");
             // layer2.0: conv1 (unless layer1's last tail kernel computed it), then ONE launch (K3f)
             const void* mid = mid2;
             if (!mid) {
@@ -555,18 +587,25 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
                 unsigned char* t = buf[(cur + 3) & 3]; buf[(cur + 3) & 3] = buf[(cur + 1) & 3]; buf[(cur + 1) & 3] = t;
             }
         } else {
+            run.note(L == 1 ? "layer2.0: generic path, one launch per convolution (downsample branch inside conv3)"
+                            : "layer3.0: generic path, one launch per convolution (downsample branch inside conv3)");
             CK(bottleneck(Lr[0], face, L == 1 ? mid2 : nullptr));
         }
         face /= 2;
         const bool fused = h16 && (L == 1 ? (face == 28 || face == 64) : (face == 14 || face == 32));
         if (!fused) {
-            for (size_t b = 1; b < Lr.size(); ++b) CK(bottleneck(Lr[b], face, nullptr));
+            run.note(L == 1 ? "layer2.1-3: GENERIC path, one launch per convolution (the fused tail kernel needs a 16-bit type and 28x28 / 64x64 faces)"
+                            : "layer3.1-5: GENERIC path, one launch per convolution (the fused tail kernel needs a 16-bit type and 14x14 / 32x32 faces)");
+            for (size_t b = 1; b < Lr.size(); ++b) { at(L + 1, (int)b); CK(bottleneck(Lr[b], face, nullptr)); }
             continue;
         }
+        run.note(L == 1 ? "layer2.1-3: conv1 + ONE fused tail launch per Bottleneck (K3e; at 28x28 faces the next block's conv1 rides on the tail)"
+                        : "layer3.1-5: conv1 + ONE fused tail launch per Bottleneck (K3e, C = 256)");
         const bool chain = L == 1 && face == 28;          // the next block's conv1 rides on the tail kernel
         bool have_mid = L == 1 && l2_mid1;                // other(1) holds this block's conv1 output
         for (size_t b = 1; b < Lr.size(); ++b) {
             CBlock& B = Lr[b];
+            at(L + 1, (int)b);
             if (!have_mid)
                 CK(run.conv(B.c1, buf[cur], n_img, face, face, nullptr, 0, other(1), 0, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr));
             if (dry) { have_mid = chain && B.w1f; continue; }
@@ -585,10 +624,14 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
         }
     }
     // ---- layer4: per convolution (conv2 on the clip-resident kernel at 7x7 / 16x16 faces)
-    for (CBlock& B : R.layer[3]) {
-        CK(bottleneck(B, face, nullptr));
-        if (&B == &R.layer[3][0]) face /= 2;
+    run.note("layer4: one launch per convolution (conv2 clip-resident or on small tiles by cp360_conv_prefer_clip; downsample inside conv3)");
+    for (size_t b = 0; b < R.layer[3].size(); ++b) {
+        at(4, (int)b);
+        CK(bottleneck(R.layer[3][b], face, nullptr));
+        if (b == 0) face /= 2;
     }
+    run.note("CAM: 1x1 convolution with the shifted fc.weight, raw f32 scores (split-K reduced by an f32 finish when the planner splits)");
+    run.where = "CAM";
     if (!dry) cp360_set_launch_order(old_order);
     // ---- CAM: raw f32 scores [n_img, face, face, num_classes] straight into the caller's buffer (no bias / activation)
     CK(run.conv(R.cam, buf[cur], n_img, face, face, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, 0, true, false, dry ? (float*)1 : cam_out, 0,
@@ -603,6 +646,23 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
 }
 
 }  // namespace
+
+extern "C" int cp360_resnet_plan_describe(cp360_ctx* ctx, int n_img, int cube_dim, char* buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return CP360_ERR_NULL;
+    std::string text;
+    char head[160];
+    snprintf(head, sizeof(head), "static stage, %d faces of %d^2, %s:", n_img, cube_dim,
+             ctx->rn.dtype == CP360_F32 ? "f32" : (ctx->rn.dtype == CP360_F16 ? "f16" : "bf16"));
+    text = head;
+    text += "\n";
+    ResnetWs w;
+    const int rc = resnet_run(ctx, true, nullptr, n_img, cube_dim, nullptr, nullptr, nullptr, 0, nullptr, &w, &text);
+    if (rc) return rc;
+    const size_t n = text.size() < cap - 1 ? text.size() : cap - 1;
+    memcpy(buf, text.data(), n);
+    buf[n] = 0;
+    return (int)n;
+}
 
 extern "C" size_t cp360_resnet_workspace_bytes(cp360_ctx* ctx, int n_img, int cube_dim) {
     if (!ctx) return 0;

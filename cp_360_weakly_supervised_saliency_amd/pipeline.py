@@ -44,13 +44,24 @@ class SaliencyEngine:
         # fp16 has a 5-bit exponent (max 65504) where bf16 has f32's range (the reference runs fp32,
         # class_activation_model.py:55-64).  When the fp16 static stage was chosen BY DEFAULT for a bf16 engine, EVERY batch
         # is checked: the window min / max kernel - which reads every CAM score anyway - poisons a window's (min, max) pair
-        # with NaN when it meets an inf / NaN (csrc/misc.hip), and the engine reads those 8 bytes per clip back after the
-        # batch.  A non-finite pair (a checkpoint or a clip whose activations exceed fp16's range) switches the static stage
-        # to bf16 for good and recomputes THIS batch - never silently wrong: ``static_precision`` / ``fp16_fallback`` say
-        # what runs, and bench.py reports them.  The read-back makes the host wait for the batch (it cannot queue the next
-        # one early: about one launch latency per batch).  An explicit static_precision='fp16' (or precision='fp16') is
-        # honoured as given and not checked; ``nonfinite()`` lets a caller check any batch.
+        # with NaN when it meets an inf / NaN (csrc/misc.hip), and the engine copies those 8 bytes per clip to pinned host
+        # memory behind the batch.
+        #   * the FIRST batch is waited for (a checkpoint whose folded-BN scales / activations exceed fp16's range shows on
+        #     any input): non-finite -> the static stage switches to bf16 for good and the batch is recomputed;
+        #   * every LATER batch is looked at WITHOUT waiting, when a following call finds its copy complete (a blocking
+        #     read-back per batch cost 0.3 ms of a 16 ms step and 2 ms of a 6 ms one - the host could no longer queue the
+        #     next batch while the GPU worked): a non-finite pair then switches the stage to bf16 for every batch not yet
+        #     queued, records the batch in ``overflow_batches`` and warns; ``check()`` waits for everything in flight and
+        #     raises FloatingPointError if any batch overflowed.  The maps of such a batch are NaN - loud, never plausible.
+        # ``static_precision`` / ``fp16_fallback`` say what runs, and bench.py reports them.  An explicit
+        # static_precision='fp16' (or precision='fp16') is honoured as given and not checked; ``nonfinite()`` lets a caller
+        # check any batch.
         self._guard = static_precision is None and precision == 'bf16'
+        self._first_checked = False
+        self._pending = []                                 # [batch index, event, pinned [B, 2] copy of the window min / max]
+        self._free_hosts = []
+        self._batch = 0
+        self.overflow_batches = []
         self.fp16_fallback = False
         self.dtype = _lib.precision_dtype(self.static_precision)
         self.B, self.T = int(clips), int(frames)
@@ -125,6 +136,7 @@ class SaliencyEngine:
         its cached workspaces; the engine re-packs on the next call.  ``del engine`` does the same through the objects'
         finalisers (the stage objects hold their modules weakly, so there is no cycle to wait for)."""
         self._graph = None
+        self._pending = []
         for mod in (self.resnet, self.cell):
             st = mod.__dict__.get('_stage')
             if st is not None:
@@ -146,19 +158,67 @@ class SaliencyEngine:
         self.dtype = _lib.precision_dtype('bf16')
         self.fp16_fallback = True
         self._guard = False
+        self._graph = None                                 # (captured launches are the fp16 ones)
+
+    def _guard_on(self):
+        return self._guard and self.static_precision == 'fp16'
+
+    def _queue_flag(self):
+        """Copy this batch's window min / max pairs to pinned memory behind the batch (8 bytes per clip, no wait)."""
+        host = self._free_hosts.pop() if self._free_hosts else \
+            torch.empty(tuple(self.runner.minmax.shape), dtype=torch.float32).pin_memory()
+        host.copy_(self.runner.minmax, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((self._batch, ev, host))
+
+    def _poll(self, wait=False):
+        """Look at the flags whose copies are complete (all of them with ``wait``); True when a batch overflowed."""
+        bad = False
+        while self._pending and (wait or self._pending[0][1].query()):
+            idx, ev, host = self._pending.pop(0)
+            if wait:
+                ev.synchronize()
+            if not bool(torch.isfinite(host).all()):
+                bad = True
+                self.overflow_batches.append(idx)
+            self._free_hosts.append(host)
+        if len(self._pending) > 8:                         # the GPU is far behind: do not let the queue grow without bound
+            return self._poll(wait=True) or bad
+        return bad
+
+    def check(self):
+        """Wait for every batch queued so far and raise FloatingPointError if the fp16 static stage overflowed on any of
+        them (their maps are NaN); the engine has switched to bf16 by then, so re-running those batches gives finite maps."""
+        if self._poll(wait=True) and self._guard_on():
+            self._fallback_to_bf16()
+        if self.overflow_batches:
+            raise FloatingPointError("fp16 static stage overflowed (non-finite CAM scores) on batch(es) %s; the engine now runs "
+                                     "the static stage in bf16 - re-run those batches" % self.overflow_batches)
 
     def _forward(self, frames):
         B, T = frames.shape[:2]
         if (B, T) != (self.B, self.T):
             raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
         flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._guard_on() and not capturing and self._poll():
+            import warnings
+            warnings.warn("fp16 static stage overflowed on batch(es) %s (their maps are NaN): switching the static stage to bf16"
+                          % self.overflow_batches)
+            self._fallback_to_bf16()
         self.static_stage(flat)
         sal = self.temporal_stage()
-        # every batch (never during graph capture - replays are checked in __call__): see __init__
-        if self._guard and self.static_precision == 'fp16' and not torch.cuda.is_current_stream_capturing() and self.nonfinite():
-            self._fallback_to_bf16()
-            self.static_stage(flat)
-            sal = self.temporal_stage()
+        if self._guard_on() and not capturing:             # see __init__
+            if not self._first_checked:
+                self._first_checked = True
+                if self.nonfinite():                       # the first batch is waited for and repaired in place
+                    self._fallback_to_bf16()
+                    self.static_stage(flat)
+                    sal = self.temporal_stage()
+            else:
+                self._queue_flag()
+        self._batch += 1
         return sal
 
     def __call__(self, frames):
@@ -168,12 +228,17 @@ class SaliencyEngine:
             if getattr(self, '_graph', None) is not None:
                 if frames.shape != self._graph_in.shape or frames.dtype != self._graph_in.dtype:
                     raise ValueError("graph captured for %s %s frames" % (tuple(self._graph_in.shape), self._graph_in.dtype))
-                self._graph_in.copy_(frames)
-                self._graph.replay()
-                if self._guard and self.static_precision == 'fp16' and self.nonfinite():
-                    self._graph = None                     # the captured launches are the fp16 ones: back to eager, in bf16
+                if self._guard_on() and self._poll():      # an earlier replay overflowed: back to eager launches, in bf16
+                    import warnings
+                    warnings.warn("fp16 static stage overflowed on batch(es) %s (their maps are NaN): switching the static "
+                                  "stage to bf16 (eager launches; capture again for graph replay)" % self.overflow_batches)
                     self._fallback_to_bf16()
                     return self._forward(frames)
+                self._graph_in.copy_(frames)
+                self._graph.replay()
+                if self._guard_on():
+                    self._queue_flag()
+                self._batch += 1
                 return self._graph_out
             return self._forward(frames)
 

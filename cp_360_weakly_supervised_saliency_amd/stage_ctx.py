@@ -133,6 +133,16 @@ class ResnetStage(_Stage):
         torch.cuda.current_stream().synchronize()          # the f32 sources (possibly temporaries) may go now
         self.stamp = stamp
 
+    def describe(self, n_img, cube_dim):
+        """cp360_resnet_plan_describe: the launch plan of the static stage for ``n_img`` faces of ``cube_dim``^2 as text - one
+        line per layer saying whether a fused kernel or the generic per-convolution path runs (cube sizes other than 224 /
+        512 and f32 take the generic path), and the tile / split-K choice of every generic launch."""
+        self._load()
+        buf = C.create_string_buffer(1 << 15)
+        n = lib().cp360_resnet_plan_describe(self.ctx.h, int(n_img), int(cube_dim), buf, len(buf))
+        check(n if n < 0 else 0)
+        return buf.value.decode()
+
     def forward(self, faces_p3, cam_out=None, want_feat=True):
         """faces_p3 [6N, cd+6, cd+6, 4] (model dtype) -> (cam f32 [6N, h, w, classes], layer4 [6N, h, w, 2048] or None)."""
         self._load()

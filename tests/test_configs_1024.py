@@ -121,3 +121,29 @@ def test_c4_shard_4_clips_x_16_frames_batched(shard, prec):
             want = s['refs'][b][1].transpose(0, 1, 3, 4, 2).reshape(T, 294, 1000)
             mn, mx = want.min(), want.max()
             assert np.max(np.abs((cam[b] - mn) / (mx - mn) - (want - mn) / (mx - mn))) <= 1e-3, b
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_c2_variant_cube_256_pipeline(prec):
+    """SURVEY 8, "C2 ... cd=256 optional variant" (the reference's only smoke test uses 256-pixel faces, model/cube_pad.py:256-261):
+    a 1024x2048 clip through cube 256 -> layer4 8x8 -> ConvLSTM at 8x8 faces -> 16x32 map, against the oracle end to end.
+    None of the fused kernels is specialised to this geometry: the static stage takes the per-convolution path
+    (cp360_resnet_plan_describe says so) and the ConvLSTM the generic ring kernel (6 * 64 = 384 pixels per cube do not fit the
+    clip-resident tile)."""
+    from cp_360_weakly_supervised_saliency_amd.pipeline import SaliencyEngine
+    cd, t = 256, 3
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=2)
+    clip = synth.clip_u8(41, t, H, W)
+    ref = ph.oracle_pipeline(clip, rs, cs, cd)
+    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=1, frames=t, precision=prec)
+    sal = eng(torch.from_numpy(clip[None]).cuda()).cpu().numpy()[0]
+    assert sal.shape == ref.shape == (16, 32)
+    err = float(np.max(np.abs(sal - ref)))
+    print('cube 256 %s: map max|d| %.2e, CC(build, oracle) %.6f' % (prec, err, o_metrics.corr_coeff(sal, ref)))
+    if prec == 'fp32':
+        assert err <= 1e-3                                                        # the north-star fp32 bound
+    else:
+        assert err <= 5e-3 and o_metrics.corr_coeff(sal, ref) >= 0.9999
+    plan = eng.resnet.__dict__['_stage'].describe(6 * t, cd)
+    assert 'layer1: GENERIC path' in plan and 'layer3.1-5: GENERIC path' in plan

@@ -14,10 +14,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 D=/tmp/exp_$V
 rm -rf $D && mkdir -p $D/pkg/csrc $D/include
 cp $R/cp_360_weakly_supervised_saliency_amd/csrc/*.hip $R/cp_360_weakly_supervised_saliency_amd/csrc/*.h $D/pkg/csrc/
-cp $R/include/cp360.h $D/include/
+cp $R/include/cp360.h $R/include/cp360_internal.h $D/include/
 cd $D/pkg/csrc
 python3 $R/tools/exp_patch.py conv_igemm.hip "$V"
-sed -i 's#"../../include/cp360.h"#"'$D'/include/cp360.h"#' common.h
+sed -i 's#"../../include/cp360_internal.h"#"'$D'/include/cp360_internal.h"#' common.h
 for f in *.hip; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -c $f -o ${f%.hip}.o & done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so *.o
 echo $D/libcp360.so

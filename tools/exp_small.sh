@@ -7,7 +7,7 @@ mkdir -p $R/tools/_exp
 for V in nomma noglobal nolds; do
   D=/tmp/exp_small_$V
   rm -rf $D && mkdir -p $D && cp -r $R/cp_360_weakly_supervised_saliency_amd/csrc $D/ && cd $D/csrc && rm -f conv_small.o libcp360.so
-  sed -i 's#"../../include/cp360.h"#"'$R'/include/cp360.h"#' common.h
+  sed -i 's#"../../include/cp360_internal.h"#"'$R'/include/cp360_internal.h"#' common.h
   python3 - "$V" <<'PY'
 import sys
 v = sys.argv[1]

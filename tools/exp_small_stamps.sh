@@ -8,7 +8,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/tools/_exp
 D=/tmp/exp_small_stamps
 rm -rf $D && mkdir -p $D && cp -r $R/cp_360_weakly_supervised_saliency_amd/csrc $D/ && cd $D/csrc && rm -f conv_small.o libcp360.so
-sed -i 's#"../../include/cp360.h"#"'$R'/include/cp360.h"#' common.h
+sed -i 's#"../../include/cp360_internal.h"#"'$R'/include/cp360_internal.h"#' common.h
 python3 - <<'PY'
 s = open('conv_small.hip').read()
 def sub(a, b, n=1):
