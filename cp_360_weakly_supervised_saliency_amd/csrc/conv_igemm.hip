@@ -1585,6 +1585,7 @@ extern "C" size_t cp360_conv_partial_bytes(const cp360_conv_desc* d) {
 struct ConvPlan {
     int bn, bm, slots, splits;
     double cost;
+    long long wgs = 0;           // workgroups of the launch (tiles x splits)
 };
 
 static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slots, double t_step) {
@@ -1604,6 +1605,7 @@ static ConvPlan plan_candidate(const cp360_conv_desc* d, int bn, int bm, int slo
         if (s == 1 || cost < best.cost) {
             best.splits = s;
             best.cost = cost;
+            best.wgs = wgs * s;
         }
     }
     return best;
@@ -1649,6 +1651,7 @@ static ConvPlan plan_small(const cp360_conv_desc* d) {
         if (s == 1 || cost < best.cost) {
             best.splits = s;
             best.cost = cost;
+            best.wgs = W;
         }
     }
     return best;
@@ -1660,8 +1663,11 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
     ConvPlan best = plan_big(d);
     if (d->tile_px == 6464) return plan_small(d);
     if (d->tile_px == 0 && small_eligible(d)) {
+        // the small tiles when the model says so - or when the best big-tile launch cannot even give every CU a workgroup
+        // (the two cost models are calibrated separately, and the big-tile one is optimistic exactly there: layer1's conv3
+        // + downsample of ONE frame: modelled 19 us on 147 workgroups, measured 47; the small tiles: 21)
         const ConvPlan sm = plan_small(d);
-        if (sm.cost < best.cost) best = sm;
+        if (sm.cost < best.cost || best.wgs < 256) best = sm;
     }
     return best;
 }
@@ -1682,6 +1688,7 @@ static ConvPlan plan_big(const cp360_conv_desc* d) {
             if (s == 1 || cost < best.cost) {
                 best.splits = s;
                 best.cost = cost;
+                best.wgs = (long long)wgs * s;
             }
         }
         return best;
