@@ -52,8 +52,9 @@ def CAM(input_cubemap, input_equi, model, feature_layer_name, weight_layer_name,
         raise ValueError("this build accelerates the ResNet-50 CAM path only (layer4 / fc.weight)")
     if class_const:
         raise NotImplementedError("class_const needs imagenet_labeldict.npz, which the reference does not ship")
-    model.eval()
-    dev = next(model.parameters()).device
+    if model.training:                                   # (a full .eval() walk per call is 0.8 ms of this per-frame path)
+        model.eval()
+    dev = model.fc.weight.device
     if dev.type != 'cuda':
         raise RuntimeError("CAM runs on the GPU only (HIP kernels); move the model with .cuda()")
     dt = _lib.precision_dtype(model.precision)
@@ -65,8 +66,17 @@ def CAM(input_cubemap, input_equi, model, feature_layer_name, weight_layer_name,
         score, feat = cam_device(x4, model)
         cube_score = ops.nhwc_to_nchw(score).cpu().numpy()
         cubic_feature = ops.nhwc_to_nchw(feat, out_dtype=torch.float32).cpu().numpy()
-    w = model.state_dict()[weight_layer_name].detach().float().cpu().numpy()
-    weight_softmax = np.squeeze(np.array(w, copy=True))
-    if np.min(weight_softmax) < 0:
-        weight_softmax -= np.min(weight_softmax)
-    return cube_score[:, :num_class], cubic_feature, weight_softmax
+    # weight_softmax: fc.weight, shifted by its minimum when that is negative (class_activation_model.py:46-52).  8 MB of
+    # device -> host copy plus two passes over it per call: cached per (storage, version) of the parameter.  The reference
+    # hands out a fresh array every call; this one is shared between calls and therefore read-only.
+    wt = model.fc.weight
+    key = (wt.data_ptr(), wt._version, str(wt.device))
+    cached = model.__dict__.get('_cam_weight_softmax')
+    if cached is None or cached[0] != key:
+        w = wt.detach().float().cpu().numpy()
+        weight_softmax = np.squeeze(np.array(w, copy=True))
+        if np.min(weight_softmax) < 0:
+            weight_softmax -= np.min(weight_softmax)
+        weight_softmax.flags.writeable = False
+        model.__dict__['_cam_weight_softmax'] = cached = (key, weight_softmax)
+    return cube_score[:, :num_class], cubic_feature, cached[1]
