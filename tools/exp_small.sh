@@ -4,7 +4,7 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd)
 mkdir -p $R/tools/_exp
-for V in nomma noglobal nolds; do
+for V in ${VARIANTS:-nomma noglobal nolds whot ahot}; do
   D=/tmp/exp_small_$V
   rm -rf $D && mkdir -p $D && cp -r $R/cp_360_weakly_supervised_saliency_amd/csrc $D/ && cd $D/csrc && rm -f conv_small.o libcp360.so
   sed -i 's#"../../include/cp360_internal.h"#"'$R'/include/cp360_internal.h"#' common.h
@@ -19,9 +19,12 @@ def sub(a, b):
 if v == 'nomma':      # no MFMAs: the fragments are consumed by an empty asm
     sub('                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]), acc[i][j], 0, 0, 0);',
         '                    asm volatile("" :: "v"(a[i][e]), "v"(b[j][e]));')
-if v == 'noglobal':   # every global load hits the zero page
-    sub('sa = *reinterpret_cast<const u32x4*>(wrow + (size_t)tap * p.c_pad + c0);', 'sa = *reinterpret_cast<const u32x4*>(g_zero16);')
-    sub('const long long mask = (long long)(((e - src_cin) >> 31) & ~(roff >> 31));', 'const long long mask = 0;')
+if v == 'noglobal':   # every global load hits the 16 zero bytes of g_zero16 (one L1-resident line)
+    sub('"v"(wvoff), "s"(wsb), "v"(av), "s"(asb)', '"v"(0u), "s"(reinterpret_cast<const T*>(g_zero16)), "v"(0u), "s"(reinterpret_cast<const T*>(g_zero16))')
+if v == 'whot':       # weights: every tile reads the FIRST tile's 64 rows (hot in every XCD's L2); activations real
+    sub('const T* wtile = reinterpret_cast<const T*>(p.w) + (size_t)n0 * p.k_total;', 'const T* wtile = reinterpret_cast<const T*>(p.w);')
+if v == 'ahot':       # activations: every tile reads the FIRST tile's pixels (offset table of tile 0); weights real
+    sub('            const int m = m0 + r;\n            int off = -1;', '            const int m = r;\n            int off = -1;')
 if v == 'nolds':      # fragments are not re-read from LDS (stores and barriers stay)
     sub('            frag_load(0, fa, fb);\n            lds_store(1, sa1, sb1);', '            if (it == 0) frag_load(0, fa, fb);\n            lds_store(1, sa1, sb1);')
     sub('            frag_load(1, fa, fb);\n            lds_store(0, sa0, sb0);', '            lds_store(0, sa0, sb0);')
