@@ -25,6 +25,7 @@
 // and the second source (the Bottleneck's downsample branch as one more 1x1 "tap" of conv3's K loop,
 // resnet_cubic.py:99-100).
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -349,6 +350,317 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(const ConvK p) {
     }
 }
 
+// ------------------------------------------------------------------ f32 form: one wave per SIMD, fillers inside the MFMA gaps
+// What the ablations of the 8-wave kernel above say ("The one-frame regime"): with EVERY load served from
+// one L1-resident line it still takes 0.70 us per f32 step against 0.43 of MFMA time, and the chain without any MFMA
+// (barrier, fragment reads, LDS stores, address arithmetic, load issue) takes 0.29 us - the two add.  A wave issues in order:
+// its ~45 non-MFMA instructions of a step and their LDS round trip run either before or after its block of MFMAs, and the
+// partner wave's MFMA stream slows them further.  In f32 an MFMA occupies the pipe for 32 cycles but the issuing wave for 8:
+// here ONE wave per SIMD issues the step's 32 MFMAs and places one or two of the other instructions in each gap (the placement
+// is pinned with sched_barrier; cdna_hip_programming.md, 4-wave attention structure: "budget every MFMA gap to <= 5 issues"):
+// the next step's eight fragment reads, the staged chunks' LDS stores, the address update and the four global loads.
+// Everything else - tile, work mapping, source-offset table, epilogue, split-K, second source - is the kernel above.
+__global__ __launch_bounds__(256, 2) void conv_small_f32_kernel(const ConvK p) {
+    typedef float T;
+    constexpr int BN = 64, BM = 64, NT = 256;
+    constexpr int EPC = 4, BK = 32;
+    constexpr int STAGE = (BN + BM) * 128;
+    constexpr int MAX_TAPS = CP360_SMALL_MAX_TAPS;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    int n0, m0, split;
+    {
+        const int nwg = p.nt * p.mt * p.splits;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
+        int nt_i, mt_i;
+        if (p.m_fast) {
+            mt_i = w % p.mt;
+            const int rest = w / p.mt;
+            nt_i = rest % p.nt;
+            split = rest / p.nt;
+        } else {
+            nt_i = w % p.nt;
+            const int rest = w / p.nt;
+            mt_i = rest % p.mt;
+            split = rest / p.mt;
+        }
+        n0 = nt_i * BN;
+        m0 = mt_i * BM;
+    }
+    const int chunk = tid & 7, row0 = tid >> 3;        // this thread's chunk of weight rows row0, row0 + 32 and pixel rows row0, row0 + 32
+
+    __shared__ int offtab[MAX_TAPS * BM];              // see conv_small_kernel
+    {
+        const int ntap_all = p.ntap + (p.c_in2 > 0 ? 1 : 0);
+        const CubePadGeom geom{p.h_in, p.pad, p.pad, p.pad, p.pad};
+        for (int t = tid; t < ntap_all * BM; t += NT) {
+            const int tp = t >> 6, r = t & 63;
+            const int m = m0 + r;
+            int off = -1;
+            if (m < p.M) {
+                const int img = m / p.hw_out, rem = m - img * p.hw_out;
+                const int oy = rem / p.w_out, ox = rem - oy * p.w_out;
+                if (tp >= p.ntap) {
+                    off = ((img * p.h_in2 + oy * p.sy2) * p.w_in2 + ox * p.sx2) * p.pix_stride2;
+                } else {
+                    const int ky = tp / p.kw, kx = tp - ky * p.kw;
+                    const int py = oy * p.sy + ky, px = ox * p.sx + kx;
+                    int pix;
+                    if (p.pad_mode) {
+                        const int grp = img / 6, f = img - grp * 6;
+                        pix = grp * 6 * p.h_in * p.w_in + cubepad_src(f, py, px, geom);
+                    } else {
+                        pix = (img * p.h_in + py) * p.w_in + px;
+                    }
+                    off = pix * p.pix_stride;
+                }
+            }
+            offtab[t] = off;
+        }
+    }
+    __syncthreads();
+    const T* in = reinterpret_cast<const T*>(p.in);
+    const T* in2 = reinterpret_cast<const T*>(p.in2);
+    const T* src = in;
+    int src_cin = p.c_in, src_cpad = p.c_pad;
+    int roff0, roff1;
+    unsigned avoff0 = 0, avoff1 = 0;
+    auto set_tap = [&](int tap) __attribute__((always_inline)) {
+        const bool second = tap >= p.ntap;
+        roff0 = offtab[tap * BM + row0];
+        roff1 = offtab[tap * BM + row0 + 32];
+        avoff0 = (unsigned)((roff0 < 0 ? 0 : roff0) + chunk * EPC) * 4u;
+        avoff1 = (unsigned)((roff1 < 0 ? 0 : roff1) + chunk * EPC) * 4u;
+        src = second ? in2 : in;
+        src_cin = second ? p.c_in2 : p.c_in;
+        src_cpad = second ? p.c_pad2 : p.c_pad;
+    };
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    const int first_steps = p.ntap * p.steps_per_tap;
+    int tap, c0;
+    if (s_begin < first_steps) {
+        tap = s_begin / p.steps_per_tap;
+        c0 = (s_begin - tap * p.steps_per_tap) * BK;
+    } else {
+        tap = p.ntap;
+        c0 = (s_begin - first_steps) * BK;
+    }
+    const unsigned wvoff0 = (unsigned)(row0 * p.k_total + chunk * EPC) * 4u;
+    const unsigned wvoff1 = wvoff0 + (unsigned)(32 * p.k_total) * 4u;
+    const T* wtile = reinterpret_cast<const T*>(p.w) + (size_t)n0 * p.k_total;
+    const int nloc = s_end - s_begin;
+    int issued = 0;
+
+    // four staging sets (the K steps it+2 .. it+5 at iteration it): weight chunks a0 / a1, activation chunks b0 / b1, masks
+    u32x4 sA0[4], sA1[4], sB0[4], sB1[4];
+    int sM0[4], sM1[4];
+    const T* cur_w = wtile;                               // uniform bases of the step being requested
+    const T* cur_a = src;
+    auto advance = [&]() __attribute__((always_inline)) {  // (uniform) the next step to request; past the end: repeat the last
+        if (issued > 0 && issued < nloc) {
+            c0 += BK;
+            if (c0 >= src_cpad) {
+                c0 = 0;
+                ++tap;
+                set_tap(tap);
+            }
+        }
+        ++issued;
+        cur_w = wtile + (size_t)tap * p.c_pad + c0;
+        cur_a = src + c0;
+    };
+#define CP360_S4_LOADW(DST, VOFF) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(DST) : "v"(VOFF), "s"(cur_w) : "memory")
+#define CP360_S4_LOADA(DST, MSK, VOFF, ROFF)                                                       \
+    {                                                                                              \
+        MSK = ((c0 + chunk * EPC - src_cin) >> 31) & ~((ROFF) >> 31);                              \
+        const unsigned av_ = (VOFF) & (unsigned)(MSK);                                             \
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(DST) : "v"(av_), "s"(cur_a) : "memory"); \
+    }
+#define CP360_S4_REQUEST(S)                                                                        \
+    {                                                                                              \
+        advance();                                                                                 \
+        CP360_S4_LOADW(sA0[S], wvoff0);                                                            \
+        CP360_S4_LOADW(sA1[S], wvoff1);                                                            \
+        CP360_S4_LOADA(sB0[S], sM0[S], avoff0, roff0);                                             \
+        CP360_S4_LOADA(sB1[S], sM1[S], avoff1, roff1);                                             \
+    }
+    // the four chunks of staging set S have landed (the 12 loads of the other three sets may be in flight); invalid rows / K tail -> 0
+#define CP360_S4_LANDED(S)                                                                         \
+    {                                                                                              \
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(sA0[S]), "+v"(sA1[S]), "+v"(sB0[S]), "+v"(sB1[S]) :: "memory"); \
+        sB0[S].x &= (unsigned)sM0[S]; sB0[S].y &= (unsigned)sM0[S]; sB0[S].z &= (unsigned)sM0[S]; sB0[S].w &= (unsigned)sM0[S]; \
+        sB1[S].x &= (unsigned)sM1[S]; sB1[S].y &= (unsigned)sM1[S]; sB1[S].z &= (unsigned)sM1[S]; sB1[S].w &= (unsigned)sM1[S]; \
+    }
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    const int st_off = lds_swz(row0, chunk), st_off1 = lds_swz(row0 + 32, chunk);
+    int fa_off[2][2], fb_off[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa_off[kk][i] = lds_swz(wn * 32 + i * 16 + lrow, kk * 4 + lchunk);
+            fb_off[kk][i] = BN * 128 + lds_swz(wm * 32 + i * 16 + lrow, kk * 4 + lchunk);
+        }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nloc > 0) {
+        u32x4 fa[2][2][2], fb[2][2][2];                   // two fragment sets [set][kk][block]
+        set_tap(tap);
+        CP360_S4_REQUEST(0)                               // steps 0 .. 3
+        CP360_S4_REQUEST(1)
+        CP360_S4_REQUEST(2)
+        CP360_S4_REQUEST(3)
+        CP360_S4_LANDED(0)
+        *reinterpret_cast<u32x4*>(lds + st_off) = sA0[0];
+        *reinterpret_cast<u32x4*>(lds + st_off1) = sA1[0];
+        *reinterpret_cast<u32x4*>(lds + BN * 128 + st_off) = sB0[0];
+        *reinterpret_cast<u32x4*>(lds + BN * 128 + st_off1) = sB1[0];
+        CP360_S4_REQUEST(0)                               // step 4
+        CP360_S4_LANDED(1)
+        *reinterpret_cast<u32x4*>(lds + STAGE + st_off) = sA0[1];
+        *reinterpret_cast<u32x4*>(lds + STAGE + st_off1) = sA1[1];
+        *reinterpret_cast<u32x4*>(lds + STAGE + BN * 128 + st_off) = sB0[1];
+        *reinterpret_cast<u32x4*>(lds + STAGE + BN * 128 + st_off1) = sB1[1];
+        CP360_S4_REQUEST(1)                               // step 5
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[0][kk][i] = *reinterpret_cast<const u32x4*>(lds + fa_off[kk][i]);
+                fb[0][kk][i] = *reinterpret_cast<const u32x4*>(lds + fb_off[kk][i]);
+            }
+        // One K step: the 32 MFMAs of step IT on fragment set CUR (LDS buffer BUF holds it), and in their gaps - pinned in this
+        // order - the eight reads of step IT+1's fragments (buffer BUF ^ 1, stored in the previous iteration) into set CUR ^ 1,
+        // the LDS stores of staging set S (step IT+2; its fragments of step IT left buffer BUF an iteration ago) into buffer BUF,
+        // the address update and the four loads of step IT+6 into the set just stored.
+        // MFMA m = (kk, e, i, j): two MFMAs on the same accumulator are four issues apart.
+#define CP360_S4_MF(CUR, M)                                                                        \
+        {                                                                                          \
+            constexpr int kk_ = (M) >> 4, e_ = ((M) >> 2) & 3, i_ = ((M) >> 1) & 1, j_ = (M) & 1;  \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[CUR][kk_][i_][e_]), __uint_as_float(fb[CUR][kk_][j_][e_]), \
+                                                               acc[i_][j_], 0, 0, 0);             \
+        }
+#define CP360_S4_PIN __builtin_amdgcn_sched_barrier(0);
+#define CP360_S4_STEP(CUR, BUF, S)                                                                 \
+        {                                                                                          \
+            unsigned char* rd_ = lds + ((BUF) ^ 1) * STAGE;                                        \
+            unsigned char* wr_ = lds + (BUF) * STAGE;                                              \
+            __syncthreads();                                                                       \
+            CP360_S4_PIN                                                                           \
+            CP360_S4_MF(CUR, 0)  fa[(CUR) ^ 1][0][0] = *reinterpret_cast<const u32x4*>(rd_ + fa_off[0][0]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 1)  fb[(CUR) ^ 1][0][0] = *reinterpret_cast<const u32x4*>(rd_ + fb_off[0][0]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 2)  fa[(CUR) ^ 1][0][1] = *reinterpret_cast<const u32x4*>(rd_ + fa_off[0][1]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 3)  fb[(CUR) ^ 1][0][1] = *reinterpret_cast<const u32x4*>(rd_ + fb_off[0][1]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 4)  fa[(CUR) ^ 1][1][0] = *reinterpret_cast<const u32x4*>(rd_ + fa_off[1][0]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 5)  fb[(CUR) ^ 1][1][0] = *reinterpret_cast<const u32x4*>(rd_ + fb_off[1][0]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 6)  fa[(CUR) ^ 1][1][1] = *reinterpret_cast<const u32x4*>(rd_ + fa_off[1][1]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 7)  fb[(CUR) ^ 1][1][1] = *reinterpret_cast<const u32x4*>(rd_ + fb_off[1][1]); CP360_S4_PIN \
+            CP360_S4_MF(CUR, 8)  CP360_S4_LANDED(S) CP360_S4_PIN                                   \
+            CP360_S4_MF(CUR, 9)  *reinterpret_cast<u32x4*>(wr_ + st_off) = sA0[S]; CP360_S4_PIN    \
+            CP360_S4_MF(CUR, 10) *reinterpret_cast<u32x4*>(wr_ + st_off1) = sA1[S]; CP360_S4_PIN   \
+            CP360_S4_MF(CUR, 11) *reinterpret_cast<u32x4*>(wr_ + BN * 128 + st_off) = sB0[S]; CP360_S4_PIN  \
+            CP360_S4_MF(CUR, 12) *reinterpret_cast<u32x4*>(wr_ + BN * 128 + st_off1) = sB1[S]; CP360_S4_PIN \
+            CP360_S4_MF(CUR, 13) advance(); CP360_S4_PIN                                           \
+            CP360_S4_MF(CUR, 14) CP360_S4_LOADW(sA0[S], wvoff0); CP360_S4_PIN                      \
+            CP360_S4_MF(CUR, 15) CP360_S4_LOADW(sA1[S], wvoff1); CP360_S4_PIN                      \
+            CP360_S4_MF(CUR, 16) CP360_S4_LOADA(sB0[S], sM0[S], avoff0, roff0) CP360_S4_PIN        \
+            CP360_S4_MF(CUR, 17) CP360_S4_LOADA(sB1[S], sM1[S], avoff1, roff1) CP360_S4_PIN        \
+            CP360_S4_MF(CUR, 18) CP360_S4_MF(CUR, 19) CP360_S4_MF(CUR, 20) CP360_S4_MF(CUR, 21)    \
+            CP360_S4_MF(CUR, 22) CP360_S4_MF(CUR, 23) CP360_S4_MF(CUR, 24) CP360_S4_MF(CUR, 25)    \
+            CP360_S4_MF(CUR, 26) CP360_S4_MF(CUR, 27) CP360_S4_MF(CUR, 28) CP360_S4_MF(CUR, 29)    \
+            CP360_S4_MF(CUR, 30) CP360_S4_MF(CUR, 31)                                              \
+            CP360_S4_PIN                                                                           \
+        }
+        // K step s travels in staging set s & 3 (steps 0 and 1 were stored by the prologue, their sets re-requested as 4 and 5)
+        for (int it = 0; it < nloc; it += 4) {
+            CP360_S4_STEP(0, 0, 2)
+            if (it + 1 >= nloc) break;
+            CP360_S4_STEP(1, 1, 3)
+            if (it + 2 >= nloc) break;
+            CP360_S4_STEP(0, 0, 0)
+            if (it + 3 >= nloc) break;
+            CP360_S4_STEP(1, 1, 1)
+        }
+#undef CP360_S4_STEP
+#undef CP360_S4_PIN
+#undef CP360_S4_MF
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sA0[0]), "+v"(sA0[1]), "+v"(sA0[2]), "+v"(sA0[3]), "+v"(sA1[0]), "+v"(sA1[1]), "+v"(sA1[2]),
+                     "+v"(sA1[3]) :: "memory");
+        asm volatile("" : "+v"(sB0[0]), "+v"(sB0[1]), "+v"(sB0[2]), "+v"(sB0[3]), "+v"(sB1[0]), "+v"(sB1[1]), "+v"(sB1[2]), "+v"(sB1[3]) :: "memory");
+    }
+#undef CP360_S4_LANDED
+#undef CP360_S4_REQUEST
+#undef CP360_S4_LOADA
+#undef CP360_S4_LOADW
+
+    // ---- epilogue: a lane owns channels n .. n+7 of pixel m for each of its two pixel blocks (as conv_small_kernel)
+    const int ml = lane & 15;
+    const int n = n0 + wn * 32 + (lane >> 4) * 8;
+    if (n >= p.c_out) return;
+    float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!p.partial && p.bias) {
+        const float4 t0 = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 t1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        bb[0] = t0.x; bb[1] = t0.y; bb[2] = t0.z; bb[3] = t0.w; bb[4] = t1.x; bb[5] = t1.y; bb[6] = t1.z; bb[7] = t1.w;
+    }
+    const T* res = reinterpret_cast<const T*>(p.res);
+    T* outp = reinterpret_cast<T*>(p.out);
+    u32x4 rr[2][2];
+    if (!p.partial && res) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wm * 32 + j * 16 + ml;
+            const T* sp = m < p.M ? res + (size_t)m * p.ld_res + n : reinterpret_cast<const T*>(g_zero16);
+            rr[j][0] = *reinterpret_cast<const u32x4*>(sp);
+            rr[j][1] = *reinterpret_cast<const u32x4*>(m < p.M ? sp + 4 : sp);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 32 + j * 16 + ml;
+        if (m >= p.M) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = acc[0][j][e];
+            v[4 + e] = acc[1][j][e];
+        }
+        if (p.partial) {
+            float* dst = p.partial + ((size_t)split * p.M + m) * p.c_out;
+            store4(dst + (p.slab_rows ? slab_col(n) : n), v);
+            store4(dst + (p.slab_rows ? slab_col(n + 4) : n + 4), v + 4);
+            continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e];
+        if (res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += __uint_as_float(rr[j][0][e]);
+                v[4 + e] += __uint_as_float(rr[j][1][e]);
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        T* dst = outp + (size_t)m * p.ld_out + p.out_coff + n;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 }  // namespace
 
 void cp360_launch_conv_small(ConvK& k, int dtype, hipStream_t st) {
@@ -357,7 +669,10 @@ void cp360_launch_conv_small(ConvK& k, int dtype, hipStream_t st) {
     // share whichever operand panel is larger through the XCD's L2
     k.m_fast = ((long long)k.c_out * k.k_total > (long long)k.M * k.kh * k.kw * k.c_in) ? 1 : 0;
     dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
-    if (dtype == CP360_F32) hipLaunchKernelGGL((conv_small_kernel<float>), grid, dim3(512), 0, st, k);
+    // f32: one wave per SIMD with the fillers inside the MFMA gaps (CP360_SMALL_F32=8 keeps the 8-wave form as an A/B path)
+    static const int f32_form = []() { const char* e = getenv("CP360_SMALL_F32"); return e ? atoi(e) : 4; }();
+    if (dtype == CP360_F32 && f32_form != 8) hipLaunchKernelGGL(conv_small_f32_kernel, grid, dim3(256), 0, st, k);
+    else if (dtype == CP360_F32) hipLaunchKernelGGL((conv_small_kernel<float>), grid, dim3(512), 0, st, k);
     else if (dtype == CP360_F16) hipLaunchKernelGGL((conv_small_kernel<f16_raw>), grid, dim3(512), 0, st, k);
     else hipLaunchKernelGGL((conv_small_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
 }

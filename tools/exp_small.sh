@@ -16,11 +16,16 @@ def sub(a, b):
     global s
     assert a in s, a
     s = s.replace(a, b)
-if v == 'nomma':      # no MFMAs: the fragments are consumed by an empty asm
+if v in ('nomma', 'bare'):      # no MFMAs: the fragments are consumed by an empty asm
     sub('                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[i][e]), __uint_as_float(b[j][e]), acc[i][j], 0, 0, 0);',
         '                    asm volatile("" :: "v"(a[i][e]), "v"(b[j][e]));')
-if v == 'noglobal':   # every global load hits the 16 zero bytes of g_zero16 (one L1-resident line)
+if v in ('noglobal', 'bare'):   # every global load hits the 16 zero bytes of g_zero16 (one L1-resident line)
     sub('"v"(wvoff), "s"(wsb), "v"(av), "s"(asb)', '"v"(0u), "s"(reinterpret_cast<const T*>(g_zero16)), "v"(0u), "s"(reinterpret_cast<const T*>(g_zero16))')
+if v == 'prio':       # the load block runs at raised priority (is the loader starved of issue slots by the partner's MFMA stream?)
+    sub('            frag_load(BUF, fa, fb);                                                                  \\\n', '            __builtin_amdgcn_s_setprio(3); frag_load(BUF, fa, fb);                                   \\\n')
+    sub('            next_gload(SA, SB, SM);                                  /* step IT+5 */                 \\\n', '            next_gload(SA, SB, SM); __builtin_amdgcn_s_setprio(0);                                    \\\n')
+if v == 'nobar':      # no barrier inside the K loop (races: timing only)
+    sub('            __syncthreads();                                                                         \\\n', '                                                                                                     \\\n')
 if v == 'whot':       # weights: every tile reads the FIRST tile's 64 rows (hot in every XCD's L2); activations real
     sub('const T* wtile = reinterpret_cast<const T*>(p.w) + (size_t)n0 * p.k_total;', 'const T* wtile = reinterpret_cast<const T*>(p.w);')
 if v == 'ahot':       # activations: every tile reads the FIRST tile's pixels (offset table of tile 0); weights real
