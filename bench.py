@@ -490,8 +490,8 @@ def cpu_anchor(reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--precision', default=os.environ.get('CP360_PRECISION', 'bf16'), choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--static-precision', default='', choices=['', 'fp32', 'bf16', 'fp16'],
                     help='arithmetic type of the static stage (ResNet-50 + CAM); default: fp16 under --precision bf16 '

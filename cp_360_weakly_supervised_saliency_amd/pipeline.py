@@ -93,6 +93,8 @@ class SaliencyEngine:
         self.cam = torch.empty((self.B, self.T, 6 * self.w * self.w, input_size), dtype=torch.float32,
                                device=self.device)
         self._mm_host = None                               # pinned copy of the runner's [B, 2] window min / max
+        if self._guard:                                    # pinned flag buffers up front: hipHostMalloc inside a timed step is a 1-2 ms hiccup
+            self._free_hosts = [torch.empty((self.B, 2), dtype=torch.float32).pin_memory() for _ in range(4)]
 
     def static_stage(self, frames):
         """frames u8/f32 [F, H, W, 3] on the device -> CAM f32 [F, 6*w*w, 1000] written
