@@ -374,6 +374,36 @@ def level1_bench(dev, precision='fp32', reps=5):
                     'to_equi_nn + torch.max per window; PCIe copies and NCHW<->NHWC conversions of every call included'}
 
 
+def stream_bench(dev, H, W, cd, B, T, precision, steps, warmup):
+    """The headline workload as a STREAM of batches (serving): SaliencyEngine.stream() runs the static stage of batch k+1 on a
+    second HIP stream beside the ConvLSTM of batch k.  Timed over `steps` batches INCLUDING the pipeline's fill (first static
+    stage alone) and drain (last ConvLSTM alone); same bits per batch as the headline path (tests/test_dropin_level1.py)."""
+    rs = synth.resnet50_state(seed=1)
+    cs = synth.clstm_state(seed=2)
+    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=B, frames=T, precision=precision, device=dev)
+    del rs, cs
+    frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + b, T, H, W)) for b in range(B)]).to(dev)
+    for _ in eng.stream(frames for _ in range(warmup + 1)):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for sal in eng.stream(frames for _ in range(steps)):
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert n == steps and bool(torch.isfinite(sal).all())
+    static_dtype = DTYPE[eng.static_precision]
+    eng.close()
+    del eng, frames
+    torch.cuda.empty_cache()
+    return {'name': 'C4 per-GPU shard as a stream of batches: static stage of batch k+1 beside the ConvLSTM of batch k (SaliencyEngine.stream)',
+            'value': round(B * T * steps / dt, 3), 'unit': 'frames/s', 'ms_per_step': round(1000.0 * dt / steps, 3), 'steps': steps,
+            'warmup': warmup, 'dtype': DTYPE[precision], 'static_stage_dtype': static_dtype,
+            'what': 'two HIP streams; fill and drain of the two-stage pipeline inside the timed region; maps of batch k returned while '
+                    'batch k+1 is in its static stage'}
+
+
 def sliding_bench(dev, precision='bf16', n_frames=64, seq_len=5, reps=5):
     """The reference's temporal workload as it runs it (temporal_model/test_temporal.py:57-62, config.yaml:34): a stride-1
     sliding window of seq_len 5 over ONE video's cube_feat sequence - every window is its own min / max normalisation,
@@ -599,6 +629,7 @@ def main():
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
             add('C4 per-GPU shard, return_all_steps: a map after every ConvLSTM step ([4, 16, 14, 28])',
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, all_steps=True)
+            sec.append(stream_bench(dev, 1024, 2048, 224, 4, 16, args.precision, 10, 2))
             sec.append(sliding_bench(dev))
             sec.append(level1_bench(dev))
             line['secondary'] = sec

@@ -93,14 +93,16 @@ class SaliencyEngine:
         self.cam = torch.empty((self.B, self.T, 6 * self.w * self.w, input_size), dtype=torch.float32,
                                device=self.device)
         self._mm_host = None                               # pinned copy of the runner's [B, 2] window min / max
+        self._cam2, self._side = None, None                # stream(): second CAM buffer and the static stage's stream
         if self._guard:                                    # pinned flag buffers up front: hipHostMalloc inside a timed step is a 1-2 ms hiccup
             self._free_hosts = [torch.empty((self.B, 2), dtype=torch.float32).pin_memory() for _ in range(4)]
 
-    def static_stage(self, frames):
+    def static_stage(self, frames, cam=None):
         """frames u8/f32 [F, H, W, 3] on the device -> CAM f32 [F, 6*w*w, 1000] written
-        into self.cam (frame-major, NHWC)."""
+        into self.cam (frame-major, NHWC; ``cam``: another buffer of the same shape)."""
         F = frames.shape[0]
-        cam_flat = self.cam.view(self.B * self.T, 6 * self.w * self.w, -1)
+        cam = self.cam if cam is None else cam
+        cam_flat = cam.view(self.B * self.T, 6 * self.w * self.w, -1)
         for lo in range(0, F, self.frame_chunk):
             hi = min(F, lo + self.frame_chunk)
             chunk = frames[lo:hi]
@@ -109,10 +111,76 @@ class SaliencyEngine:
             # K1 writes the CubePad(3)-padded faces directly (one pass instead of project + pad)
             x4 = self.e2c.to_cube_batch(chunk, out_dtype=self.dtype, layout='nhwc4p3')
             cam_device(x4, self.resnet, out=cam_flat[lo:hi], padded=True, want_feat=False)     # CAM conv writes the clip buffer directly
-        return self.cam
+        return cam
 
     def temporal_stage(self, cam=None):
         return self.runner.run(self.cam if cam is None else cam, return_all_steps=self.return_all_steps)
+
+    def stream(self, batches):
+        """Software-pipelined form for a STREAM of batches (serving): a generator that takes an iterable of frame batches
+        ([B, T, H, W, 3] each) and yields one saliency tensor per batch, in order - the static stage of batch k+1 runs on a
+        second HIP stream beside the ConvLSTM of batch k (the clip kernel owns every CU's LDS, so the static stage's
+        workgroups get its tails and launch gaps: +2-3 % throughput, tools/overlap_probe.py).  Results are the same bits as
+        ``__call__`` gives batch by batch (same kernels, same order inside each stage; the two CAM buffers alternate).  Each
+        yielded tensor is overwritten two batches later - consume or clone it.  The fp16 range guard polls as in ``__call__``
+        (a switch to bf16 takes effect for the batches whose static stage has not been queued yet)."""
+        if self._cam2 is None:
+            self._cam2 = torch.empty_like(self.cam)
+            self._side = torch.cuda.Stream(device=self.device)
+        cams = (self.cam, self._cam2)
+        main = torch.cuda.current_stream(self.device)
+        side = self._side
+        out2 = [None, None]
+        pending = None                                     # (index, cam buffer, event: its static stage is done)
+        temporal_done = [None, None]                       # events: the ConvLSTM that read cam buffer i is done
+        # (no ``with torch.no_grad()`` around the loop: a context manager held across ``yield`` would leak into the consumer)
+        for i, frames in enumerate(batches):
+            B, T = frames.shape[:2]
+            if (B, T) != (self.B, self.T):
+                raise ValueError("engine built for %dx%d clips x frames" % (self.B, self.T))
+            if self._guard_on() and self._poll():
+                import warnings
+                warnings.warn("fp16 static stage overflowed on batch(es) %s (their maps are NaN): switching the static stage "
+                              "to bf16" % self.overflow_batches)
+                main.synchronize()
+                side.synchronize()
+                self._fallback_to_bf16()
+            flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
+            buf = cams[i & 1]
+            side.wait_stream(main)                         # the frames (and everything the caller queued) are ready
+            if temporal_done[i & 1] is not None:
+                side.wait_event(temporal_done[i & 1])      # batch i-2's ConvLSTM has read this buffer
+            with torch.no_grad(), torch.cuda.stream(side):
+                self.static_stage(flat, cam=buf)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            if pending is not None:
+                yield self._stream_temporal(pending, temporal_done, out2, main)
+            pending = (i, buf, ev)
+        if pending is not None:
+            yield self._stream_temporal(pending, temporal_done, out2, main)
+
+    def _stream_temporal(self, pending, temporal_done, out2, main):
+        i, buf, ev = pending
+        main.wait_event(ev)
+        with torch.no_grad():
+            sal = self.temporal_stage(buf)
+            if out2[i & 1] is None:
+                out2[i & 1] = torch.empty_like(sal)
+            out2[i & 1].copy_(sal)                         # (the runner's map buffer is reused by the next window)
+        if self._guard_on():
+            if not self._first_checked:
+                self._first_checked = True
+                if self.nonfinite():
+                    raise FloatingPointError("fp16 static stage overflowed on the first batch of the stream: build the engine with "
+                                             "static_precision='bf16' (or run one batch through __call__ first, which repairs it)")
+            else:
+                self._queue_flag()
+        self._batch += 1
+        done = torch.cuda.Event()
+        done.record(main)
+        temporal_done[i & 1] = done
+        return out2[i & 1]
 
     # ---- hipGraph replay (launch-bound small configurations: one frame / one clip)
     def capture(self, frames):
