@@ -96,10 +96,13 @@ def main():
         out['WRITE_SIZE_KiB_per_launch'] = wr
         out['conv_igemm_clstm_bytes_per_launch'] = traffic
         lines.append('')
+        # the algorithmic bytes depend on the launch shape (M = pixels of the batch, split-K factor): derived from the
+        # write counter instead of quoted for one shape - one f32 slab of the 4000-channel output is M * 16 kB
         lines.append('ConvLSTM conv launches (grid %s): FETCH_SIZE %.0f KiB (K=36000 launches; %.0f KiB over all three '
                      'convs), WRITE_SIZE %.0f KiB per launch -> HBM traffic (2*FETCH + WRITE)*1024 = %.1f MB per '
-                     'K=36000 launch (algorithmic: 297 MB packed weights + 19 MB activations + 75 MB slabs (4 splits))'
-                     % (key, fe, sum(fv) / len(fv), wr, traffic / 1e6))
+                     'K=36000 launch (algorithmic: 295 MB packed weights + the activations once + the f32 split-K slabs = the '
+                     'write counter: %.0f MB = %.1f slabs of an M = 1176 launch (18.8 MB each) / of an M = 1536 launch (24.6 MB each: %.1f))'
+                     % (key, fe, sum(fv) / len(fv), wr, traffic / 1e6, wr * 1024 / 1e6, wr * 1024 / 18.8e6, wr * 1024 / 24.6e6))
     # per-kernel HBM bytes and GB/s: FETCH_SIZE / WRITE_SIZE averaged per launch and kernel name (counter passes),
     # duration from the kernel-trace pass
     if tr and find(os.path.join(src, 'fetch'), '*counter_collection.csv') and find(os.path.join(src, 'write'), '*counter_collection.csv'):
