@@ -77,6 +77,14 @@ def cpu_model():
     return 'unknown'
 
 
+def _safe(fn):
+    """A diagnostic value, or None when collecting it fails (never an exception after the timed region)."""
+    try:
+        return fn()
+    except Exception:                               # noqa: BLE001
+        return None
+
+
 def sync(dev):
     if torch.device(dev).type == 'cuda':
         torch.cuda.synchronize()
@@ -278,14 +286,21 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
         res['allgather_ms'] = round(cpdist.max_over_ranks(time.perf_counter() - t0, dev) * 100.0, 4)
         res['allgather_bytes_per_rank'] = int(sal.numel() * sal.element_size())
         res['map_shape'] = list(out.shape)
+    # diagnostics after the timed region: a failure here is reported in the line, it never costs the measured value
     if want_split and not static_only and not stub:
         if graph:
             eng._graph = None
-        res['stage_ms'] = stage_split(eng, frames)
+        try:
+            res['stage_ms'] = stage_split(eng, frames)
+        except Exception as e:                      # noqa: BLE001
+            res['stage_ms'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     if want_roofline and not static_only and not stub:
         if graph:
             eng._graph = None                      # the roofline pass needs eager launches to bracket
-        res['roofline'] = roofline_pass(eng, frames, precision)
+        try:
+            res['roofline'] = roofline_pass(eng, frames, precision)
+        except Exception as e:                      # noqa: BLE001
+            res['roofline'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     if static_only and not stub:
         res['roofline'] = static_roofline(res['ms_per_step'], B, T, cd, eng.static_precision)
     res['w'] = eng.w
@@ -600,7 +615,7 @@ def main():
             # attribution of one box's number (measured after the timed region): where a step's time goes, and the shader
             # clock this chip holds under a dense bf16 MFMA load (boxes differ: MI355X_MICROARCH.md, DVFS give-back)
             'stage_ms': head.get('stage_ms'),
-            'held_clock_ghz': None if args.stub_engine else ops.held_clock_ghz(dev),
+            'held_clock_ghz': None if args.stub_engine else _safe(lambda: ops.held_clock_ghz(dev)),
         }
         if args.stub_engine:
             line['stub_engine'] = True
@@ -608,13 +623,24 @@ def main():
         if world == 1 and not args.no_secondary and not args.stub_engine:
             sec = []
 
+            def guarded(name, fn):
+                """A secondary line must never cost the headline its JSON line: a failure is recorded, not raised."""
+                try:
+                    sec.append(fn())
+                except Exception as e:                      # noqa: BLE001 - reported in the line
+                    sec.append({'name': name, 'error': '%s: %s' % (type(e).__name__, str(e)[:300])})
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+
             def add(name, H2, W2, cd2, B2, T2, prec, steps, warmup, **kw):
-                r = run_workload(dev, 0, 1, H2, W2, cd2, B2, T2, prec, steps, warmup, want_roofline=True, **kw)
-                sec.append({'name': name, 'workload': workload_name(kw.get('static_only', False), B2, T2, H2, W2, cd2, r['w'],
+                def run():
+                    r = run_workload(dev, 0, 1, H2, W2, cd2, B2, T2, prec, steps, warmup, want_roofline=True, **kw)
+                    return {'name': name, 'workload': workload_name(kw.get('static_only', False), B2, T2, H2, W2, cd2, r['w'],
                                                                     None, kw.get('all_steps', False), kw.get('f32_input', False)),
-                            'dtype': DTYPE[prec], 'static_stage_dtype': r['static_dtype'], 'graph_replay': bool(kw.get('graph')), 'value': r['value'],
-                            'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': steps, 'warmup': warmup,
-                            'roofline': r['roofline']})
+                            'dtype': DTYPE[prec], 'static_stage_dtype': r['static_dtype'], 'graph_replay': bool(kw.get('graph')),
+                            'value': r['value'], 'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': steps, 'warmup': warmup,
+                            'roofline': r['roofline']}
+                guarded(name, run)
 
             add('C4 per-GPU shard, fp32 (the 1e-3 parity precision)', 1024, 2048, 224, 4, 16, 'fp32', 3, 1)
             add('C4 per-GPU shard, bf16 in BOTH stages (static stage bf16 instead of fp16)', 1024, 2048, 224, 4, 16, 'bf16', 3, 1,
@@ -629,12 +655,15 @@ def main():
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
             add('C4 per-GPU shard, return_all_steps: a map after every ConvLSTM step ([4, 16, 14, 28])',
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, all_steps=True)
-            sec.append(stream_bench(dev, 1024, 2048, 224, 4, 16, args.precision, 10, 2))
-            sec.append(sliding_bench(dev))
-            sec.append(level1_bench(dev))
+            guarded('C4 per-GPU shard as a stream of batches', lambda: stream_bench(dev, 1024, 2048, 224, 4, 16, args.precision, 10, 2))
+            guarded('reference temporal workload: sliding window', lambda: sliding_bench(dev))
+            guarded('Level-1 drop-in path', lambda: level1_bench(dev))
             line['secondary'] = sec
         if world == 1 and not args.no_cpu_baseline and not args.stub_engine:
-            line['cpu_baseline'] = cpu_baseline(args.precision, dev, args.static_precision or None)
+            try:
+                line['cpu_baseline'] = cpu_baseline(args.precision, dev, args.static_precision or None)
+            except Exception as e:                          # noqa: BLE001 - the headline line is printed whatever happens here
+                line['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         print(json.dumps(line))
     cpdist.barrier()
     if torch.distributed.is_initialized():
