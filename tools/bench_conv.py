@@ -41,6 +41,8 @@ shapes = [
     ('l4.conv1 1x1', 6 * F, 2048, 512, 7, 1, 1, 0),
     ('l3.0conv1 1x1', 6 * F, 512, 256, 28, 1, 1, 0),
     ('l4.0conv1 1x1', 6 * F, 1024, 512, 14, 1, 1, 0),
+    ('c5face.Conv2', 6 * B, 4000, 4000, 16, 3, 1, 1),      # config C5: 16x16 faces (use --clips 1)
+    ('c5face.Conv1', 6 * B, 2000, 4000, 16, 3, 1, 1),
 ]
 for name, n_img, cin, cout, n, k, s, pad in shapes:
     if args.only and args.only not in name:
