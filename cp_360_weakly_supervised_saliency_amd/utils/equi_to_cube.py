@@ -15,6 +15,10 @@ import torch
 from .. import ops
 from .sph_utils import rotx, roty, rotz
 
+# numpy dtypes uploaded as they are and converted to float32 on the device (anything else: one numpy pass on the host)
+_TORCH_CASTABLE = (np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.uint8), np.dtype(np.int16),
+                   np.dtype(np.int32), np.dtype(np.int64))
+
 # yaw, pitch, roll in degrees for back, bottom, front, left, right, top (:17-22)
 _VIEWS = ((180, 0, 0), (0, -90, 0), (0, 0, 0), (-90, 0, 0), (90, 0, 0), (0, 90, 0))
 
@@ -86,6 +90,7 @@ class Equi2Cube:
         self.cv_fixed_point = bool(cv_fixed_point)
         self._grid_dev = None
         self._grid_p3_dev = None
+        self._stage = {}                                               # pinned host buffer of to_cube's D2H copy
 
     @property
     def grid(self):
@@ -108,13 +113,28 @@ class Equi2Cube:
         """[H, W, C=3] float array -> {0..5: [cd, cd, 3]} like the reference (:112-129):
         plain bilinear remap, no normalisation.  H2D + kernel + D2H."""
         img = np.asarray(in_image)
-        x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None].to(self.device)
+        # The frame crosses PCIe in the dtype it arrives in (the reference's driver hands in the float64 ``np.array(img) /
+        # 255.0``) and is rounded to float32 on the device - the same IEEE rounding numpy's cast does, without a
+        # single-threaded pass over 6 M elements on the host.  Read-only / byte-swapped / exotic inputs: numpy converts.
+        if img.flags.writeable and img.dtype.isnative and img.dtype in _TORCH_CASTABLE:
+            x = torch.from_numpy(img).to(self.device)[None].to(torch.float32)
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None].to(self.device)
         cubes = ops.equi2cube(x, self.grid, self.output_width, torch.float32, 'nchw', scale=1.0,
                               mean=(0., 0., 0.), std=(1., 1., 1.), cv_fixed_point=self.cv_fixed_point)
-        host = cubes.permute(0, 2, 3, 1).cpu().numpy().astype(img.dtype if img.dtype.kind == 'f' else np.float32)
+        back = self._staging('out', (6, self.output_height, self.output_width, img.shape[2]), torch.float32)
+        back.copy_(cubes.permute(0, 2, 3, 1), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()           # the faces are in the (reused) pinned buffer
+        host = back.numpy().astype(img.dtype if img.dtype.kind == 'f' else np.float32)   # fresh arrays per call, as :117-118
         for idx in range(6):
             self.out[idx] = host[idx]
         return self.out
+
+    def _staging(self, name, shape, dtype):
+        buf = self._stage.get(name)
+        if buf is None or tuple(buf.shape) != tuple(shape) or buf.dtype != dtype:
+            buf = self._stage[name] = torch.empty(shape, dtype=dtype).pin_memory()
+        return buf
 
     def to_cube_batch(self, frames, out_dtype=torch.float32, layout='nhwc4', normalize=True):
         """Device path: frames [F, H, W, 3] u8 / f32 tensor on the GPU -> the

@@ -225,6 +225,32 @@ def test_equi2cube_matches_oracle(H, W, cd):
     assert np.max(np.abs(bf[..., :3].transpose(0, 3, 1, 2) - want)) <= 2e-2
 
 
+def test_to_cube_staging_keeps_the_reference_semantics():
+    """``Equi2Cube.to_cube`` (equi_to_cube.py:112-129) through its pinned staging buffers: fresh arrays per call (a later
+    call does not change what an earlier one returned), the input's floating dtype, and the same faces for a float64, a
+    float32, a read-only and a non-contiguous view of the same frame (the last two take the numpy conversion path)."""
+    H, W, cd = 256, 512, 64
+    e = Equi2Cube(cd, (H, W))
+    a = synth.frame_u8(5, H, W).astype(np.float64) / 255.0
+    b = synth.frame_u8(6, H, W).astype(np.float64) / 255.0
+    fa = dict(e.to_cube(a))
+    keep = {k: v.copy() for k, v in fa.items()}
+    fb = e.to_cube(b)
+    for f in range(6):
+        assert fa[f].dtype == np.float64 and np.array_equal(fa[f], keep[f]) and not np.array_equal(fb[f], keep[f])
+        assert np.max(np.abs(keep[f] - o_e2c.to_cube(a, cd)[f])) <= 2e-6
+    f32 = dict(e.to_cube(a.astype(np.float32)))                 # (the dict itself is the object's, as in the reference)
+    ro = a.copy()
+    ro.flags.writeable = False
+    fro = dict(e.to_cube(ro))
+    wide = np.zeros((H, W, 4))
+    wide[..., :3] = a
+    fnc = e.to_cube(wide[..., :3])
+    for f in range(6):
+        assert f32[f].dtype == np.float32 and np.max(np.abs(f32[f] - keep[f])) <= 1e-6
+        assert np.array_equal(fro[f], keep[f]) and np.array_equal(fnc[f], keep[f])
+
+
 # ------------------------------------------------------------------ K6 cube -> equi
 @pytest.mark.parametrize('w', [4, 7, 8, 16])
 def test_cube2equi_golden(golden_dir, w):
