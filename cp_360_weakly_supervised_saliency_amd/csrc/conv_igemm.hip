@@ -14,8 +14,9 @@
 //   conv_igemm_dma_kernel<T,MJ>  c_out >= 256, small M: 256x128 tile, three LDS-DMA stages
 //   conv_igemm_ring_kernel<T,BM> c_out >= 256: 256x256 / 256x304 tile, four 64-byte-K stages, staggered waves
 //   conv_igemm_ring2_kernel<T>   1x1 with K of 128..512 elements, 16-bit: 256x128, two workgroups per CU
-//   conv_clip_kernel<T,FACE>     CubePad(1)+3x3 on 7x7 faces (ConvLSTM, one cube per tile) or 16x16 faces
-//                                (one face + ring per tile): activations LDS-resident, taps = row permutations
+//   conv_clip_kernel<T,MODE>     CubePad(1)+3x3 on 7x7 faces (ConvLSTM, one cube per tile), 8x8 faces (half a cube per
+//                                tile, the cube resident) or 16x16 faces (one face + ring per tile): activations
+//                                LDS-resident, taps = row permutations
 // (the stem and layer1's conv2 have their own resident-tile kernels in stem.hip / band3x3.hip)
 //
 // Tiling (wave64, MFMA 16x16):
@@ -1053,32 +1054,39 @@ __device__ __forceinline__ int clip_swz(int row) { return ((row >> 2) & 1) << 1;
 // FACE variant (16x16 faces, the ConvLSTM at cube size 512 - BASELINE config C5): a tile is ONE face (256
 // pixels, 8 + 8 pixel blocks) and the resident tile is that face WITH its CubePad(1) ring, 18 x 18 = 324
 // rows gathered through cubepad_src() at DMA time; a tap then reads row (y + ky) * 18 + x + kx.
-template <bool FACE> struct ClipGeom {
-    static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;
-    static constexpr int RROWS = FACE ? 336 : 304;               // resident rows (324 used in the FACE variant)
-    static constexpr int GROUP_ROWS = FACE ? 128 : 160;          // tile rows of wave group 0 (waves 0-3)
+// HALF variant (8x8 faces, cube size 256 - the reference's own smoke-test size, model/cube_pad.py:256-261): a cube is 384
+// pixels, more than one 304-row tile and more accumulators than a wave has, so a tile is HALF a cube (three faces = 192
+// pixels, 6 + 6 pixel blocks) while the resident tile is the WHOLE cube (384 rows: the taps of a face read its
+// neighbours); the source-row table is the clip variant's, built for the tile's half.
+// MODE: 0 = one cube per tile (faces up to 7x7), 1 = FACE, 2 = HALF.
+template <int MODE> struct ClipGeom {
+    static constexpr bool FACE = MODE == 1, HALF = MODE == 2;
+    static constexpr int BN = 256, BM = FACE ? 256 : HALF ? 192 : 304, NW = 6, NA = 2;
+    static constexpr int RROWS = FACE ? 336 : HALF ? 384 : 304;  // resident rows (324 used in the FACE variant)
+    static constexpr int GROUP_ROWS = FACE ? 128 : HALF ? 96 : 160;   // tile rows of wave group 0 (waves 0-3)
     static constexpr int XW = (RROWS - 256) / 16;                // waves that carry the resident rows past 256
     static constexpr int WSTAGE = BN * 64;                       // 16 KiB of weights per sub-step
-    static constexpr int ATILE = RROWS * 64;                     // 19 / 21 KiB: one channel block of the clip / face
+    static constexpr int ATILE = RROWS * 64;                     // 19 / 21 / 24 KiB: one channel block of the clip / face / cube
     static constexpr int TAB_ROW = 32;                           // bytes per (tap, wave group, lane row): 10 u16 + pad
     static constexpr int TAB_BYTES = 9 * 2 * 16 * TAB_ROW;
     static constexpr int OFF_ACT = NW * WSTAGE;
     static constexpr int OFF_TAB = OFF_ACT + NA * ATILE;
-    static constexpr int LDS_BYTES = OFF_TAB + TAB_BYTES;        // 146,432 B (150,528 B FACE)
+    static constexpr int LDS_BYTES = OFF_TAB + TAB_BYTES;        // 146,432 B (150,528 B FACE, 156,672 B HALF)
 };
 
-template <typename T, int MJ, int JH, bool LAG, bool FACE>
+template <typename T, int MJ, int JH, bool LAG, int MODE>
 __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, const int n0, const int clip, const int split,
                                           const int wave, const int lane, const int tid, const int wch0, const int grp) {
-    typedef ClipGeom<FACE> G;
+    typedef ClipGeom<MODE> G;
+    constexpr bool FACE = G::FACE, HALF = G::HALF;
     constexpr int BN = G::BN, BM = G::BM;
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BKS = 4 * EPC;                               // K elements per sub-step (64 bytes)
     constexpr int TAPS = 9;
     const int wrow0 = grp * G::GROUP_ROWS;
     const bool xw = wave < G::XW;                              // the waves that carry the resident rows past 256
-    const int rows_valid = FACE ? 256 : p.clip_rows;           // tile rows that are output pixels
-    const int m0 = clip * rows_valid;                          // `clip` = cube (clip mode) or face image (FACE)
+    const int rows_valid = FACE ? 256 : HALF ? 192 : p.clip_rows;   // tile rows that are output pixels
+    const int m0 = clip * rows_valid;                          // `clip` = cube (clip mode), face image (FACE) or half cube (HALF)
 
     // DMA role (as in the ring kernel): 16 rows x 4 chunks per wave-instruction, source-side swizzle
     const int drow = 16 * wave + (lane >> 2);
@@ -1102,6 +1110,8 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
                 const CubePadGeom geom{16, 1, 1, 1, 1};
                 off = (cube * 6 * 256 + cubepad_src(f, r / 18, r - (r / 18) * 18, geom)) * p.pix_stride;
             }
+        } else if (HALF) {
+            off = ((clip >> 1) * 384 + r) * p.pix_stride;     // the whole cube is resident (r < 384 = three passes)
         } else if (r < p.clip_rows && (q < 2 || xw)) {
             off = (m0 + r) * p.pix_stride;
         }
@@ -1191,6 +1201,11 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
                 int src = 0;
                 if (FACE) {
                     if (j < 8) src = ((row >> 4) + t / 3) * 18 + (row & 15) + t % 3;   // row of the padded 18x18 face
+                } else if (HALF) {
+                    if (j < 6) {                                               // pixel (clip & 1) * 192 + row of the cube
+                        const int pix = (clip & 1) * 192 + row;
+                        src = cubepad_src(pix >> 6, ((pix >> 3) & 7) + t / 3, (pix & 7) + t % 3, geom);
+                    }
                 } else if (row < p.clip_rows && (g == 0 || j < 9)) {
                     const int f = row / nn, rem = row - f * nn;
                     const int y = rem / n, x = rem - y * n;
@@ -1324,9 +1339,9 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
 }
 
 constexpr int CLIP_JH = 0;
-template <typename T, bool FACE>
+template <typename T, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
-    typedef ClipGeom<FACE> G;
+    typedef ClipGeom<MODE> G;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1342,12 +1357,15 @@ __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
         split = rest / p.nt;
     }
     constexpr int JHC = CLIP_JH;                       // MFMA columns issued in the load half of a sub-step (see clip_body)
-    if constexpr (FACE) {
-        if (wave < 4) clip_body<T, 8, JHC, false, true>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
-        else          clip_body<T, 8, JHC, true, true>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+    if constexpr (MODE == 1) {
+        if (wave < 4) clip_body<T, 8, JHC, false, 1>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 8, JHC, true, 1>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+    } else if constexpr (MODE == 2) {
+        if (wave < 4) clip_body<T, 6, JHC, false, 2>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 6, JHC, true, 2>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
     } else {
-        if (wave < 4) clip_body<T, 10, JHC, false, false>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
-        else          clip_body<T, 9, JHC, true, false>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
+        if (wave < 4) clip_body<T, 10, JHC, false, 0>(p, lds, n0, clip, split, wave, lane, tid, wave * 64, 0);
+        else          clip_body<T, 9, JHC, true, 0>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);
     }
 }
 
@@ -1534,9 +1552,10 @@ static int check_desc(const cp360_conv_desc* d) {
     if (d->slab_rows != 0 && d->slab_rows != 1) return CP360_ERR_BAD_SHAPE;
     if (d->slab_rows && d->c_out % 32 != 0) return CP360_ERR_ALIGN;
     if (d->clip_resident != 0 && d->clip_resident != 1) return CP360_ERR_BAD_SHAPE;
-    // clip-resident kernel: CubePad(1) + 3x3 stride 1 on faces whose cube (6 n^2 pixels) fits one 304-row tile
+    // clip-resident kernel: CubePad(1) + 3x3 stride 1 on faces whose cube (6 n^2 pixels) fits one 304-row tile, on 8x8 faces
+    // (half a cube per tile, the cube resident) and on 16x16 faces (one face + its ring per tile)
     if (d->clip_resident && !(d->pad_mode == 1 && d->pad == 1 && d->kh == 3 && d->kw == 3 && d->sy == 1 && d->sx == 1 &&
-                              d->h_in == d->w_in && (6 * d->h_in * d->w_in <= 304 || d->h_in == 16) && d->c_out >= 256 &&
+                              d->h_in == d->w_in && (6 * d->h_in * d->w_in <= 304 || d->h_in == 16 || d->h_in == 8) && d->c_out >= 256 &&
                               d->pix_stride >= d->c_in && d->tile_px == 0))
         return CP360_ERR_UNSUPPORTED;
     if (d->c_in2 < 0) return CP360_ERR_BAD_SHAPE;
@@ -1658,6 +1677,8 @@ static ConvPlan plan_small(const cp360_conv_desc* d) {
 }
 
 static ConvPlan plan_big(const cp360_conv_desc* d);
+// pixel tiles of the clip-resident kernel: a face at 16x16, half a cube at 8x8, otherwise a cube
+static int clip_tiles(const cp360_conv_desc* d) { return d->h_in == 16 ? d->n_img : d->h_in == 8 ? d->n_img / 3 : d->n_img / 6; }
 
 static ConvPlan plan_of(const cp360_conv_desc* d) {
     ConvPlan best = plan_big(d);
@@ -1675,9 +1696,9 @@ static ConvPlan plan_of(const cp360_conv_desc* d) {
 static ConvPlan plan_big(const cp360_conv_desc* d) {
     if (d->clip_resident) {
         // one 256-channel x clip tile per workgroup, 64-byte sub-steps; about 0.9 us per sub-step
-        const int wgs = ((d->c_out + 255) / 256) * (d->h_in == 16 ? d->n_img : d->n_img / 6);   // tile = face at 16x16
+        const int wgs = ((d->c_out + 255) / 256) * clip_tiles(d);
         const int nsub = 9 * (c_pad_of(d) / (bk_of(d->dtype) / 2));
-        const double t_sub = d->dtype == CP360_F32 ? 2.7 : 0.9;
+        const double t_sub = (d->dtype == CP360_F32 ? 2.7 : 0.9) * (d->h_in == 8 ? 0.7 : 1.0);   // (6 + 6 instead of 10 + 9 pixel blocks)
         const long long M = (long long)d->n_img * d->h_out * d->w_out;
         ConvPlan best{256, 304, 256, 1, 0.0};
         for (int s = 1; s <= 32; ++s) {
@@ -1784,9 +1805,10 @@ extern "C" int cp360_conv_plan_describe(const cp360_conv_desc* d, char* buf, siz
     const char* name;
     long long wgs;
     if (t.clip_resident) {
-        const bool face = t.h_in == 16;
-        name = face ? "conv_clip 256 ch x one 16x16 face (activations LDS-resident)" : "conv_clip 256 ch x one cube (activations LDS-resident)";
-        wgs = (long long)((t.c_out + 255) / 256) * (face ? t.n_img : t.n_img / 6);
+        name = t.h_in == 16 ? "conv_clip 256 ch x one 16x16 face (activations LDS-resident)"
+               : t.h_in == 8 ? "conv_clip 256 ch x half a cube of 8x8 faces (the cube LDS-resident)"
+                             : "conv_clip 256 ch x one cube (activations LDS-resident)";
+        wgs = (long long)((t.c_out + 255) / 256) * clip_tiles(&t);
     } else if (bm == 64) {
         name = "conv_small 64 ch x 64 px (8 waves)";
         wgs = (long long)((t.c_out + 63) / 64) * ((M + 63) / 64);
@@ -1914,15 +1936,16 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     k.epi_direct = (epi_mode && epi_ok) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (d->clip_resident) {
-        const bool face = d->h_in == 16;                         // 16x16 faces: one face (+ its CubePad ring) per tile
+        const int mode = d->h_in == 16 ? 1 : d->h_in == 8 ? 2 : 0;   // tile = a face + its ring / half a cube / a cube
         k.nt = (k.c_out + 255) / 256;
-        k.mt = face ? d->n_img : d->n_img / 6;
+        k.mt = clip_tiles(d);
         k.m_fast = 1;
         dim3 grid((unsigned)(k.nt * k.mt * k.splits), 1, 1);
 #define CP360_CLIP(TT)                                                                                    \
         {                                                                                                     \
-            if (face) hipLaunchKernelGGL((conv_clip_kernel<TT, true>), grid, dim3(512), 0, st, k);            \
-            else      hipLaunchKernelGGL((conv_clip_kernel<TT, false>), grid, dim3(512), 0, st, k);           \
+            if (mode == 1)      hipLaunchKernelGGL((conv_clip_kernel<TT, 1>), grid, dim3(512), 0, st, k);     \
+            else if (mode == 2) hipLaunchKernelGGL((conv_clip_kernel<TT, 2>), grid, dim3(512), 0, st, k);     \
+            else                hipLaunchKernelGGL((conv_clip_kernel<TT, 0>), grid, dim3(512), 0, st, k);     \
         }
         if (d->dtype == CP360_F32) CP360_CLIP(float)
         else if (d->dtype == CP360_F16) CP360_CLIP(f16_raw)

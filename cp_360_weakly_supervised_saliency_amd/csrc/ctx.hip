@@ -132,7 +132,7 @@ int pack_conv(Owned& own, CConv& c, int dtype, const float* w, const float* scal
 }
 
 bool clip_geometry(const CConv& c, int n_img, int h, int w) {
-    return c.clip_ok && h == w && (6 * h * w <= 304 || h == 16) && n_img % 6 == 0;
+    return c.clip_ok && h == w && (6 * h * w <= 304 || h == 8 || h == 16) && n_img % 6 == 0;
 }
 
 void fill_desc(const CConv& c, int dtype, int n_img, int h_in, int w_in, int splits, int ld_out, int out_coff,

@@ -413,11 +413,11 @@ class Conv:
         ld_out = self.c_out if out is None else out.shape[3]
         ld_res = 0 if residual is None else residual.shape[3]
         L = lib()
-        # clip-resident kernel: whole cubes of <= 304 pixels (faces <= 7x7) or one 16x16 face + ring per tile
+        # clip-resident kernel: whole cubes of <= 304 pixels (faces <= 7x7), half a cube of 8x8 faces, or one 16x16 face + ring per tile
         cr = self.clip_resident_ok if clip_resident is None else bool(clip_resident)
-        cr = int(cr and h_in == w_in and (6 * h_in * w_in <= 304 or h_in == 16) and n_img % 6 == 0 and tile_px == 0)
+        cr = int(cr and h_in == w_in and (6 * h_in * w_in <= 304 or h_in in (8, 16)) and n_img % 6 == 0 and tile_px == 0)
         if clip_resident and not cr:
-            raise ValueError("clip_resident needs CubePad(1)+3x3 stride 1 on faces of at most 7x7, or 16x16")
+            raise ValueError("clip_resident needs CubePad(1)+3x3 stride 1 on faces of at most 7x7, 8x8 or 16x16")
         if cr and clip_resident is None and not self.clip_only:
             # both layouts can be packed: few cubes x few channels (layer4's conv2 of one frame) run better on the small
             # tap-major tiles (cp360_conv_prefer_clip; same rule in csrc/ctx.hip)

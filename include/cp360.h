@@ -188,8 +188,10 @@ typedef struct {
                          every tap reads the clip's activations from an LDS-resident
                          tile (cubepad halo never leaves the cube).  Also 16x16 faces
                          (cube size 512): one face per tile, resident with its CubePad
-                         ring (18 x 18 rows).  Must be the same at pack and forward
-                         time; other geometries: UNSUPPORTED                         */
+                         ring (18 x 18 rows); and 8x8 faces (cube size 256): half a
+                         cube (three faces) per tile with the whole cube resident.
+                         Must be the same at pack and forward time; other
+                         geometries: UNSUPPORTED                                     */
     int slab_rows;    /* 1: the f32 `partial` sums keep the packed row order inside each
                          32-channel group (the 4-channel group of channel n sits at
                          column (n & ~31) + ((n >> 3) & 3) * 4 + ((n >> 2) & 1) * 16), so

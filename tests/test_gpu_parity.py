@@ -748,7 +748,7 @@ def test_short_k_two_workgroup_kernel(prec, cin, use_res):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
-@pytest.mark.parametrize('n', [7, 5, 3, 16])
+@pytest.mark.parametrize('n', [7, 5, 3, 16, 8])
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('splits', [1, 3, 7])
 def test_clip_resident_conv(n, prec, splits):
@@ -758,7 +758,8 @@ def test_clip_resident_conv(n, prec, splits):
     c_out = 264: ragged channel tile; splits 3 and 7 cut inside channel blocks; residual + ReLU run the
     LDS epilogue with rows past the clip masked."""
     dt = _TDT[prec]
-    n_img, cin, cout, k = (18 if n < 16 else 12), 104, 264, 3        # n = 16: the FACE variant (tile = face + ring)
+    # n = 16: the FACE variant (tile = face + ring); n = 8: the HALF variant (tile = three faces, the cube resident)
+    n_img, cin, cout, k = (18 if n < 16 else 12), 104, 264, 3
     x = hashrng.normal(9400 + n, (n_img, cin, n, n))
     w = hashrng.normal(9401, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
     bias = hashrng.normal(9403, (cout,), 0, 0.1)

@@ -43,6 +43,8 @@ shapes = [
     ('l4.0conv1 1x1', 6 * F, 1024, 512, 14, 1, 1, 0),
     ('c5face.Conv2', 6 * B, 4000, 4000, 16, 3, 1, 1),      # config C5: 16x16 faces (use --clips 1)
     ('c5face.Conv1', 6 * B, 2000, 4000, 16, 3, 1, 1),
+    ('w8.Conv2    ', 6 * B, 4000, 4000, 8, 3, 1, 1),        # cube 256: 8x8 faces
+    ('w8.Conv1    ', 6 * B, 2000, 4000, 8, 3, 1, 1),
 ]
 for name, n_img, cin, cout, n, k, s, pad in shapes:
     if args.only and args.only not in name:
@@ -53,7 +55,7 @@ for name, n_img, cin, cout, n, k, s, pad in shapes:
     kw = {'splits': args.splits} if args.splits else {}
     if args.tile_px:
         kw['tile_px'] = args.tile_px
-    if args.clip_resident >= 0 and k == 3 and n <= 7 and cout >= 256:
+    if args.clip_resident >= 0 and k == 3 and (n <= 7 or n in (8, 16)) and cout >= 256:
         kw['clip_resident'] = bool(args.clip_resident)
     if args.residual:
         ho_ = (n + 2 * pad - k) // s + 1
