@@ -17,6 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cp_360_weakly_supervised_saliency_amd import ops, _lib
 
 L = _lib.lib()
+ORDER = int(os.environ.get('CP360_ORDER', '0'))       # 1: descending work-item order (does the slow XCD follow the work or the silicon?)
+L.cp360_set_launch_order(ORDER)
 w = torch.randn(4000, 4000, 3, 3) * 0.01
 conv = ops.Conv(w, None, torch.zeros(4000), 1, 1, True, torch.bfloat16, 'cuda')
 x = torch.randn(24, 7, 7, 4000, device='cuda').to(torch.bfloat16)
@@ -63,6 +65,22 @@ loop = np.median(t[:, :, 2] - t[:, :, 1])
 say('launch window (earliest entry -> latest exit): %.2f us; median K loop %.2f us = %.1f %% of it; prologue + epilogue + skew = the rest'
     % (win, loop, 100.0 * loop / win))
 say('latest exit - median exit: %.2f us (the tail during which some CUs already idle)' % (t[:, :, 3].max() - np.median(t[:, :, 3].max(axis=1))))
+# who is slow?  blockIdx -> XCD (blockIdx & 7) and, through the kernel's XCD-contiguous mapping, -> (clip, channel tile, split)
+bid = np.arange(nwg)
+xcd = bid & 7
+w_item = xcd * (nwg // 8) + (bid >> 3)
+if ORDER == 1:
+    w_item = nwg - 1 - w_item
+clip_i, tile_i, split_i = w_item % 4, (w_item // 4) % 16, w_item // 64
+kl = (t[:, :, 2] - t[:, :, 1]).max(axis=1)
+say('')
+say('K loop (us, the slower half of each workgroup), mean by XCD:   ' + '  '.join('%d: %.1f' % (k, kl[xcd == k].mean()) for k in range(8)))
+say('K loop mean by clip (the four workgroups that share a weight stream): ' + '  '.join('%d: %.1f' % (k, kl[clip_i == k].mean()) for k in range(4)))
+say('K loop mean by K split: ' + '  '.join('%d: %.1f' % (k, kl[split_i == k].mean()) for k in range(4)))
+say('K loop mean by channel tile: ' + '  '.join('%d: %.1f' % (k, kl[tile_i == k].mean()) for k in range(16)))
+say('spread inside an XCD (max - min), mean over XCDs: %.1f us; between XCD means: %.1f us'
+    % (np.mean([kl[xcd == k].max() - kl[xcd == k].min() for k in range(8)]),
+       max(kl[xcd == k].mean() for k in range(8)) - min(kl[xcd == k].mean() for k in range(8))))
 text = '\n'.join(lines) + '\n'
 print(text)
 if len(sys.argv) > 1:

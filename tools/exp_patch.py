@@ -91,20 +91,20 @@ for v in variants:
             "        if (LAG) CP360_CLIP_TAIL()\n        if (lane == 0) {\n            for (int k = 0; k < 5; ++k) atomicAdd(&g_stamp[wave][k], (unsigned long long)st_acc[k]);\n"
             "            atomicAdd(&g_stamp[wave][7], (unsigned long long)nloc);\n        }\n#undef CP360_CLIP_STEP")
     if v == 'clip_phases':     # clip kernel: per-workgroup stamps of prologue / K loop / epilogue (s_memrealtime, 100 MHz, chip-wide)
-        sub('template <bool FACE> struct ClipGeom {',
+        sub('template <int MODE> struct ClipGeom {',
             '__device__ unsigned long long g_phase[1024 * 2 * 4];\n'
             'extern "C" int cp360_debug_phases(unsigned long long* out_host, int n) {\n'
             '    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_phase), (size_t)n * 8) == hipSuccess ? 0 : -7;\n}\n'
             '#define CP360_PHASE(K) { if (lane == 0 && (wave & 3) == 0 && blockIdx.x < 1024) { __builtin_amdgcn_sched_barrier(0); '
             'g_phase[(blockIdx.x * 2 + (wave >> 2)) * 4 + (K)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } }\n'
-            'template <bool FACE> struct ClipGeom {')
+            'template <int MODE> struct ClipGeom {')
         sub("        constexpr int YW = 2 * (G::NW - 2);\n        const int na = xw ? 3 : 2;\n        int it = 0;",
             "        constexpr int YW = 2 * (G::NW - 2);\n        const int na = xw ? 3 : 2;\n        int it = 0;\n        CP360_PHASE(1)")
         sub("        if (LAG) CP360_CLIP_TAIL()\n#undef CP360_CLIP_STEP", "        if (LAG) CP360_CLIP_TAIL()\n        CP360_PHASE(2)\n#undef CP360_CLIP_STEP")
         # kernel entry / exit: stamps around the body calls
         sub("    constexpr int JHC = CLIP_JH;                       // MFMA columns issued in the load half of a sub-step (see clip_body)\n",
             "    constexpr int JHC = CLIP_JH;\n    CP360_PHASE(0)\n")
-        i = s.index('        else          clip_body<T, 9, JHC, true, false>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);')
+        i = s.index('        else          clip_body<T, 9, JHC, true, 0>(p, lds, n0, clip, split, wave, lane, tid, (wave - 4) * 64, 1);')
         j = s.index('\n', s.index('}', i)) + 1
         s = s[:j] + '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    CP360_PHASE(3)\n' + s[j:]
     if v == 'clip_loadprio':   # clip kernel: a wave raises its priority for its LOAD half (LDS reads, DMA issue) and drops it for COMPUTE
@@ -130,9 +130,9 @@ for v in variants:
     if v.startswith('clip_jh'):   # clip kernel: MFMA columns issued in the load half (0 = pure load / compute halves)
         sub('constexpr int CLIP_JH = 0;', 'constexpr int CLIP_JH = %d;' % int(v[7:]))
     if v == 'clip_nw7':        # clip kernel: seven weight stages
-        sub('static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 7, NA = 2;')
+        sub('static constexpr int BN = 256, BM = FACE ? 256 : HALF ? 192 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : HALF ? 192 : 304, NW = 7, NA = 2;')
     if v == 'clip_nw5':
-        sub('static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : 304, NW = 5, NA = 2;')
+        sub('static constexpr int BN = 256, BM = FACE ? 256 : HALF ? 192 : 304, NW = 6, NA = 2;', 'static constexpr int BN = 256, BM = FACE ? 256 : HALF ? 192 : 304, NW = 5, NA = 2;')
     if v == 'clip_prio':       # clip kernel: static priority for the lagging half (waves 4-7)
         sub('        if (wave < 4) clip_body<T, 10, JHC, false, false>', '        if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n        if (wave < 4) clip_body<T, 10, JHC, false, false>')
     if v == 'fullline':
