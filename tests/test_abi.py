@@ -135,3 +135,70 @@ def test_round2_entry_points_validate_without_gpu():
     assert L.cp360_stem_pool_forward(_lib.F32, one, one, None, one, one, 6, 224, None) != 0
     old = L.cp360_set_launch_order(2)
     assert L.cp360_set_launch_order(1) == 2 and L.cp360_set_launch_order(7) == 1 and L.cp360_set_launch_order(old) == 0
+
+
+def _desc(dtype, n_img, face, c_in, c_out, k, stride=1, clip_resident=0):
+    d = _lib.ConvDesc()
+    pad = 1 if k == 3 else 0
+    ho = (face + 2 * pad - k) // stride + 1
+    for key, v in dict(dtype=dtype, n_img=n_img, h_in=face, w_in=face, c_in=c_in, pix_stride=c_in, kh=k, kw=k, sy=stride, sx=stride,
+                       h_out=ho, w_out=ho, c_out=c_out, pad_mode=1 if pad else 0, pad=pad, ld_out=c_out, out_coff=0, ld_res=0,
+                       relu=1, splits=1, clip_resident=clip_resident).items():
+        setattr(d, key, v)
+    return d
+
+
+@pytest.mark.parametrize('cube', [224, 256, 512])
+def test_launch_planner_over_the_network_shapes(cube):
+    """The host-side launch planner (cp360_conv_suggest_splits / cp360_conv_plan_describe, csrc/conv_igemm.hip) on every
+    convolution shape of the path (resnet_cubic.py:85-175, clstm.py:56-64) x 1 / 4 / 16 / 64 frames x the three dtypes: a plan
+    exists, its split count is a valid one, the workspace it implies is what cp360_conv_partial_bytes reports, and the
+    description names a kernel.  No GPU involved: this is the part of the library that decides what gets launched."""
+    L = _lib.lib()
+    f1 = cube // 4
+    shapes = [(f1, 64, 64, 1, 1), (f1, 64, 64, 3, 1), (f1, 64, 256, 1, 1), (f1, 256, 64, 1, 1),
+              (f1, 256, 128, 1, 1), (f1, 128, 128, 3, 2), (f1 // 2, 128, 512, 1, 1), (f1 // 2, 512, 128, 1, 1),
+              (f1 // 2, 128, 128, 3, 1), (f1 // 2, 512, 256, 1, 1), (f1 // 2, 256, 256, 3, 2), (f1 // 4, 256, 1024, 1, 1),
+              (f1 // 4, 1024, 256, 1, 1), (f1 // 4, 256, 256, 3, 1), (f1 // 4, 1024, 512, 1, 1), (f1 // 4, 512, 512, 3, 2),
+              (f1 // 8, 512, 2048, 1, 1), (f1 // 8, 2048, 512, 1, 1), (f1 // 8, 512, 512, 3, 1), (f1 // 8, 2048, 1000, 1, 1),
+              (f1 // 8, 2000, 4000, 3, 1), (f1 // 8, 4000, 4000, 3, 1)]
+    buf = C.create_string_buffer(256)
+    seen = set()
+    for frames in (1, 4, 16, 64):
+        for dtype in (_lib.F32, _lib.BF16, _lib.F16):
+            for face, cin, cout, k, s in shapes:
+                d = _desc(dtype, 6 * frames, face, cin, cout, k, s)
+                sp = L.cp360_conv_suggest_splits(C.byref(d))
+                assert 1 <= sp <= 32, (frames, dtype, face, cin, cout, k, s, sp)
+                n = L.cp360_conv_plan_describe(C.byref(d), buf, 256)
+                text = buf.value.decode()
+                assert n > 0 and text.startswith('conv_'), text
+                assert ('split-K %d' % sp) in text, (text, sp)
+                seen.add(text.split(',')[0])
+                d.splits = sp
+                ho = d.h_out
+                assert L.cp360_conv_partial_bytes(C.byref(d)) == (sp * 6 * frames * ho * ho * cout * 4 if sp > 1 else 0)
+                assert L.cp360_conv_packed_bytes(C.byref(d)) > 0
+    assert len(seen) >= 3, seen                                 # small tiles, ring tiles, narrow tiles all occur somewhere
+
+
+@pytest.mark.parametrize('face,tile,clips,want', [(7, 'one cube', 4, 4), (8, 'half a cube of 8x8 faces', 4, 2),
+                                                   (16, 'one 16x16 face', 1, 5), (7, 'one cube', 1, 16)])
+def test_clip_resident_planner(face, tile, clips, want):
+    """The clip-resident kernel's tiles (a cube at up to 7x7 faces, half a cube at 8x8, a face at 16x16) x split-K fill the
+    256 CUs: the ConvLSTM's Conv2 / Gates shape (clstm.py:59-64) at the batch sizes the bench lines use."""
+    L = _lib.lib()
+    d = _desc(_lib.BF16, 6 * clips, face, 4000, 4000, 3, 1, clip_resident=1)
+    buf = C.create_string_buffer(256)
+    assert L.cp360_conv_plan_describe(C.byref(d), buf, 256) > 0
+    text = buf.value.decode()
+    assert tile in text, text
+    sp = L.cp360_conv_suggest_splits(C.byref(d))
+    assert sp == want, (text, sp)
+    tiles = 16 * {7: clips, 8: 2 * clips, 16: 6 * clips}[face]
+    assert ('%d workgroups' % (tiles * sp)) in text, text
+    assert 200 <= tiles * sp <= 512                             # one or two rounds of the chip, never a fraction of it
+    for bad in (9, 12):                                         # other face sizes: UNSUPPORTED, not a silent generic launch
+        d2 = _desc(_lib.BF16, 6 * clips, bad, 4000, 4000, 3, 1, clip_resident=1)
+        assert L.cp360_conv_plan_describe(C.byref(d2), buf, 256) == -8
+    assert L.cp360_conv_prefer_clip(C.byref(d)) in (0, 1)
