@@ -39,8 +39,12 @@ def main():
             if 'conv_clip' in r['Kernel_Name']:
                 dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
     a = {k: sum(v) / len(v) for k, v in agg.items()}
-    lines = ['conv_clip_kernel<bf16, clip tile>: ConvLSTM Conv2 / Gates, M = 1176 (4 clips), N = 4000, K = 36000, 4 K-splits, 256 workgroups',
-             'rocprofv3 --pmc passes over tools/bench_conv.py --only clstm.Conv2 --clips 4 (per-launch averages; chip-wide sums)', '']
+    # shape of the launch (tools/pmc_clip_final.sh SHAPE=...): useful rows, padded rows, slabs, label
+    shape = 'w8.Conv2' if 'w8.Conv2' in src else 'clstm.Conv2'
+    M, MP, SL, what = {'clstm.Conv2': (1176, 1216, 4, 'clip tile>: ConvLSTM Conv2 / Gates, M = 1176 (4 clips of 7x7 faces), N = 4000, K = 36000, 4 K-splits, 256 workgroups'),
+                       'w8.Conv2': (1536, 1536, 2, 'HALF tile>: ConvLSTM Conv2 / Gates at 8x8 faces (cube 256), M = 1536 (4 clips, 8 half-cube tiles), N = 4000, K = 36000, 2 K-splits, 256 workgroups')}[shape]
+    lines = ['conv_clip_kernel<bf16, ' + what,
+             'rocprofv3 --pmc passes over tools/bench_conv.py --only %s --clips 4 (per-launch averages; chip-wide sums)' % shape, '']
     for k, v in a.items():
         lines.append('%-36s n=%-3d avg=%.5g' % (k, len(agg[k]), v))
     lines.append('')
@@ -48,13 +52,13 @@ def main():
     us = sum(dur) / len(dur) if dur else float('nan')
     kcyc = g('SQ_BUSY_CYCLES') / 32.0
     mfma = g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024.0
-    ideal = 2.0 * 1216 * 4096 * 36000 / (1024 * 1024.0)       # MFMA cycles per SIMD: padded tile flops / (1024 flop/clk/SIMD x 1024 SIMDs)
+    ideal = 2.0 * MP * 4096 * 36000 / (1024 * 1024.0)       # MFMA cycles per SIMD: padded tile flops / (1024 flop/clk/SIMD x 1024 SIMDs)
     lines.append('launch duration under the profiler: %.1f us (n=%d)' % (us, len(dur)))
     lines.append('kernel cycles (SQ_BUSY_CYCLES / 32 shader engines): %.0f -> clock held during the launch: %.2f GHz' % (kcyc, kcyc / us / 1e3))
     lines.append('MFMA pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / kernel cycles):                 %.3f  (%.0f busy cycles per SIMD; '
-                 '%.0f = the MFMAs of the padded 1216 x 4096 tile at 16 cycles each)' % (mfma / kcyc, mfma, ideal))
+                 '%.0f = the MFMAs of the padded %d x 4096 tile at 16 cycles each)' % (mfma / kcyc, mfma, ideal, MP))
     lines.append('  => fraction of the 2.5 PFLOP/s peak = MFMA busy x clock / 2.4 GHz x useful / padded flops = %.3f'
-                 % (mfma / kcyc * (kcyc / us / 1e3) / 2.4 * (1176.0 * 4000) / (1216.0 * 4096)))
+                 % (mfma / kcyc * (kcyc / us / 1e3) / 2.4 * (M * 4000.0) / (MP * 4096.0)))
     lines.append('wave cycles parked in s_waitcnt / barrier (SQ_WAIT_ANY / SQ_WAVE_CYCLES):       %.3f' % (g('SQ_WAIT_ANY') / g('SQ_WAVE_CYCLES')))
     lines.append('wave cycles stalled on issue (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES):               %.3f' % (g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES')))
     lines.append('wave cycles issuing (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES):                      %.3f' % (g('SQ_ACTIVE_INST_ANY') / g('SQ_WAVE_CYCLES')))
@@ -64,7 +68,7 @@ def main():
     tr = (2 * g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024
     lines.append('HBM traffic per launch (2 * FETCH_SIZE + WRITE_SIZE) KiB:                        %.1f MB (fetch %.1f MB, write %.1f MB)'
                  % (tr / 1e6, 2 * g('FETCH_SIZE') * 1024 / 1e6, g('WRITE_SIZE') * 1024 / 1e6))
-    lines.append('algorithmic: packed weights 295 MB + activations 2 x 9.4 MB; the 4 f32 split-K slabs add 75 MB of writes')
+    lines.append('algorithmic: packed weights 295 MB + activations 2 x %.1f MB; the %d f32 split-K slabs add %.0f MB of writes' % (M * 4000 * 2 / 1e6, SL, SL * M * 4000 * 4 / 1e6))
     open(txt, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 
