@@ -26,7 +26,7 @@ def precision_dtype(precision):
         raise ValueError("precision must be one of %s" % sorted(PRECISIONS))
 OK = 0
 # must equal CP360_VERSION of include/cp360.h (checked against the loaded library in lib())
-ABI_VERSION = 304
+ABI_VERSION = 305
 
 
 # every exported symbol of include/cp360.h - the documented boundary (checked by tests/test_abi.py)
@@ -43,7 +43,9 @@ PUBLIC_SYMBOLS = [
     'cp360_resnet_load', 'cp360_resnet_workspace_bytes', 'cp360_resnet_forward', 'cp360_clstm_load', 'cp360_clstm_workspace_bytes',
     'cp360_clstm_step', 'cp360_conv_finish_add', 'cp360_window_normalize_frames',
     'cp360_clstm_window_workspace_bytes', 'cp360_clstm_window', 'cp360_clock_probe', 'cp360_conv_prefer_clip',
-    'cp360_conv_plan_describe', 'cp360_resnet_plan_describe',
+    'cp360_conv_plan_describe', 'cp360_resnet_plan_describe', 'cp360_wino_packed_bytes', 'cp360_wino_v_bytes',
+    'cp360_wino_m_bytes', 'cp360_wino_preferred', 'cp360_wino_pack_weights', 'cp360_wino_input', 'cp360_wino_gemm',
+    'cp360_wino_output', 'cp360_wino_output_gates', 'cp360_wino_forward',
 ]
 # ... and of include/cp360_internal.h: the shape-specific fused kernels the stage contexts are built from (exported for
 # tests and the CP360_CTX=0 planner; not part of the boundary)
@@ -54,7 +56,7 @@ INTERNAL_SYMBOLS = [
     'cp360_l2block_packed_bytes', 'cp360_l2block_pack_weights', 'cp360_l2block_forward',
     'cp360_l2block_forward_next', 'cp360_set_launch_order', 'cp360_stem_pool_border_bytes',
     'cp360_stem_pool_forward', 'cp360_l3block_packed_bytes', 'cp360_l3block_pack_weights', 'cp360_l3block_forward',
-    'cp360_l2first_w3d_bytes', 'cp360_l2first_pack_w3d', 'cp360_l2first_forward',
+    'cp360_l2first_w3d_bytes', 'cp360_l2first_pack_w3d', 'cp360_l2first_forward', 'cp360_wino_gemm_raw',
 ]
 SYMBOLS = PUBLIC_SYMBOLS + INTERNAL_SYMBOLS
 
@@ -66,6 +68,11 @@ class ConvDesc(C.Structure):
         'h_out', 'w_out', 'c_out', 'pad_mode', 'pad', 'ld_out', 'out_coff', 'ld_res',
         'relu', 'splits', 'tile_px', 'clip_resident', 'slab_rows',
         'c_in2', 'pix_stride2', 'h_in2', 'w_in2', 'sy2', 'sx2')]
+
+
+class WinoDesc(C.Structure):
+    """Mirror of ``cp360_wino_desc`` (include/cp360.h)."""
+    _fields_ = [(n, C.c_int) for n in ('dtype', 'n_img', 'face', 'c_in', 'pix_stride', 'c_out', 'ld_out', 'out_coff', 'relu')]
 
 
 class ConvBn(C.Structure):
@@ -185,6 +192,18 @@ def lib():
     L.cp360_conv_prefer_clip.argtypes = [pd]
     L.cp360_conv_plan_describe.argtypes = [pd, C.c_char_p, sz]
     L.cp360_resnet_plan_describe.argtypes = [vp, i, i, C.c_char_p, sz]
+    pw = C.POINTER(WinoDesc)
+    for fn in ('cp360_wino_packed_bytes', 'cp360_wino_v_bytes', 'cp360_wino_m_bytes'):
+        getattr(L, fn).restype = sz
+        getattr(L, fn).argtypes = [pw]
+    L.cp360_wino_preferred.argtypes = [pw]
+    L.cp360_wino_pack_weights.argtypes = [pw, vp, vp, vp]
+    L.cp360_wino_input.argtypes = [pw, vp, vp, vp]
+    L.cp360_wino_gemm.argtypes = [pw, vp, vp, vp, vp]
+    L.cp360_wino_output.argtypes = [pw, vp, vp, vp, vp]
+    L.cp360_wino_output_gates.argtypes = [pw, vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, sz, vp]
+    L.cp360_wino_forward.argtypes = [pw, vp, vp, vp, vp, vp, vp, vp]
+    L.cp360_wino_gemm_raw.argtypes = [i, vp, vp, vp, i, i, i, i, i, vp]
     for name in SYMBOLS:
         getattr(L, name)          # AttributeError here = header and library disagree
     if L.cp360_version() != ABI_VERSION or L.cp360_conv_desc_bytes() != C.sizeof(ConvDesc):

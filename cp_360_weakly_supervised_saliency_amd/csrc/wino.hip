@@ -1,0 +1,608 @@
+// Winograd F(2x2, 3x3) form of CubePad(1) + 3x3 convolution (the three ConvLSTM convolutions of model/clstm.py:56-64) for the
+// 16-bit types.  A face of w x w pixels is cut into th x th tiles of 2 x 2 outputs (th = ceil(w / 2)); with
+//     U_p = (G g G^T)_p      [c_out, c_in]   one matrix per position p of the 4 x 4 transform domain (packed once)
+//     V_p = (B^T d B)_p      [tiles, c_in]   d = the 4 x 4 window of the cube-padded input behind a tile
+//     M_p = V_p . U_p^T      [tiles, c_out]  sixteen plain GEMMs, f32 sums
+//     Y   = A^T M A + bias   the tile's 2 x 2 outputs
+// the convolution needs 16 multiplies per tile and channel pair instead of 9 per pixel: 16 / 36 of the direct form's MFMAs at
+// even face sizes (8x8, 16x16), 256 / 441 at 7x7 (16 tiles cover 8 x 8 of which 49 outputs are used).  Transforms are f32 on
+// exact 16-bit values, U and V are rounded ONCE to the 16-bit type (tests/probe_winograd_numerics.py: the T = 16 window keeps
+// |dAUC-Judd|, |dCC| < 1e-4 against the oracle).  f32 stays on the direct kernels.
+//
+//   wino_in_kernel     NHWC activations (through cubepad_src) -> V   [pos][c / 32][tile][32]   (64-byte rows, tile-major)
+//   wino_gemm_kernel   256 channels x 384 tiles x one position per workgroup, both operands streamed by LDS-DMA
+//   wino_out_kernel    M [pos][tile][c_out] f32 -> A^T M A + bias (+ ReLU) -> NHWC activations, or -> the LSTM gate update
+#include "conv_common.h"
+
+namespace {
+
+constexpr int WG_BN = 256, WG_BM = 384, WG_NS = 4;
+constexpr int WG_STAGE = (WG_BN + WG_BM) * 64;             // 40 KiB per 64-byte sub-step; 4 stages = all 160 KiB of LDS
+
+struct WinoK {
+    const unsigned char* u;      // [16][nt][nsub][256][64 B]
+    const unsigned char* v;      // [16][nsub][m_pad][64 B]
+    float* m;                    // [16][m_pad][ldm]
+    int nsub, nt, mt, m_pad, ldm, c_out, reverse;
+};
+
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4); }
+
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_upto(int n);
+template <> __device__ __forceinline__ void vm_wait_upto<0>(int) { vm_wait<0>(); }
+template <int N> __device__ __forceinline__ void vm_wait_upto(int n) {
+    if (n >= N) vm_wait<N>();
+    else vm_wait_upto<N - 1>(n);
+}
+
+// One sub-step's fill, this wave's share: 2 + 3 LDS-DMA instructions of 1 KiB (16 rows x 64 B).  Both operand blocks are
+// contiguous (16 KiB of U, 24 KiB of V): "scalar base + 32-bit lane offset" addressing, M0 = the wave's LDS destination.
+// cache policy of the U (weight) / V stream loads: 0 default, 1 nt, 2 sc1, 3 sc0 sc1 (tools/wino_variants.sh A/B)
+#ifndef WINO_UPOL_ID
+#define WINO_UPOL_ID 0
+#endif
+#ifndef WINO_VPOL_ID
+#define WINO_VPOL_ID 0
+#endif
+#if WINO_UPOL_ID == 1
+#define WINO_UPOL " nt"
+#elif WINO_UPOL_ID == 2
+#define WINO_UPOL " sc1"
+#elif WINO_UPOL_ID == 3
+#define WINO_UPOL " sc0 sc1"
+#else
+#define WINO_UPOL ""
+#endif
+#if WINO_VPOL_ID == 1
+#define WINO_VPOL " nt"
+#elif WINO_VPOL_ID == 2
+#define WINO_VPOL " sc1"
+#elif WINO_VPOL_ID == 3
+#define WINO_VPOL " sc0 sc1"
+#else
+#define WINO_VPOL ""
+#endif
+__device__ __forceinline__ void fill(const unsigned char* ub, const unsigned char* vb, unsigned o0, unsigned o1, unsigned o2,
+                                     unsigned dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4" WINO_UPOL "\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %4" WINO_UPOL "\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5" WINO_VPOL "\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5" WINO_VPOL "\n\t"
+        "s_add_u32 m0, m0, 0x2000\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %5" WINO_VPOL "\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(o0), "v"(o1), "v"(o2), "s"(ub), "s"(vb), "s"(dst)
+        : "memory", "scc");
+}
+
+// K loop + slab stores of one wave: channels [wch0, +64) x tile rows [wrow0, +192) = 4 x 12 MFMA blocks (192 accumulator
+// registers).  A sub-step is a HEAD (fragment reads, the refill DMAs, the first 6 columns; a column's registers are re-loaded
+// with column 6 + j as soon as its MFMAs are issued) and a TAIL (the other 6 columns, from registers); the two waves of a
+// SIMD (w and w + 4) run half a sub-step apart, as in conv_igemm_ring_kernel<T, 304>.
+template <typename T, bool LAG>
+__device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, const int pos, const int nt_i, const int mt_i,
+                                          const int wave, const int lane, const int wch0, const int wrow0) {
+    constexpr int NS = WG_NS, D = 5, MJ = 12, JH = 6;
+    const int nsub = p.nsub;
+    const unsigned char* ub = p.u + ((size_t)(pos * p.nt + nt_i) * nsub) * (WG_BN * 64);
+    const size_t vstep = (size_t)p.m_pad * 64;
+    const unsigned char* vb = p.v + (size_t)pos * nsub * vstep + (size_t)mt_i * (WG_BM * 64);
+    // DMA role: lane l lands in row 16 * wave + (l >> 2) (+ 128 per pass), physical chunk l & 3, and fetches the logical chunk
+    const unsigned o0 = (unsigned)((16 * wave + (lane >> 2)) * 64 + ((((lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3))) << 4));
+    const unsigned o1 = o0 + 0x2000, o2 = o0 + 0x4000;
+    const unsigned lds_wave = (unsigned)(size_t)lds + (unsigned)wave * 1024;
+
+    f32x4 acc[4][MJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+        fill(ub, vb, o0, o1, o2, __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE));
+#ifndef WINO_ABL
+#define WINO_ABL 0          // timing ablations (tools/wino_variants.sh): 1 = every U block aliases the first, 2 = every V block, 4 = no MFMA
+#endif
+        if (!(WINO_ABL & 1)) ub += WG_BN * 64;
+        if (!(WINO_ABL & 2)) vb += vstep;
+    };
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (k < nsub) issue(k);
+    int stage = 0;
+    u32x4 a[4], b[JH];
+    if (LAG) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < JH; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
+    }
+#if WINO_ABL & 4
+#define WINO_MMA(cc, aa, bb) cc[0] = __uint_as_float(__float_as_uint(cc[0]) ^ aa[0] ^ bb[0])
+#else
+#define WINO_MMA(c, x, y) mma_chunk<T>(c, x, y)
+#endif
+#define WINO_HEAD(REFILL)                                                                                  \
+    {                                                                                                      \
+        const unsigned char* As = lds + stage * WG_STAGE;                                                  \
+        const unsigned char* Bs = As + WG_BN * 64;                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            a[i] = *reinterpret_cast<const u32x4*>(As + swz64(wch0 + i * 16 + lrow, lchunk));              \
+        _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                     \
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + j * 16 + lrow, lchunk));             \
+        if (REFILL) issue(stage == 0 ? NS - 1 : stage - 1);                                                \
+        _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j]);                 \
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + (JH + j) * 16 + lrow, lchunk));      \
+        }                                                                                                  \
+        stage = stage == NS - 1 ? 0 : stage + 1;                                                           \
+    }
+#define WINO_TAIL()                                                                                        \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j - JH]);            \
+    }
+#define WINO_STEP(REFILL)                                                                                  \
+    {                                                                                                      \
+        if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (!LAG) WINO_HEAD(REFILL) else WINO_TAIL()                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (!LAG) WINO_TAIL() else WINO_HEAD(REFILL)                                                       \
+    }
+    int it = 0;
+    for (; it + NS - 1 < nsub; ++it) {
+        vm_wait<(NS - 2) * D>();
+        WINO_STEP(true)
+    }
+    for (; it < nsub; ++it) {
+        vm_wait_upto<(NS - 2) * D>(min(NS - 2, nsub - 1 - it) * D);
+        WINO_STEP(false)
+    }
+    if (LAG) WINO_TAIL()
+#undef WINO_STEP
+#undef WINO_HEAD
+#undef WINO_TAIL
+
+    // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores; the four lane
+    // groups of a tile row write 64 contiguous bytes, the four blocks of a wave 256)
+    float* mp = p.m + ((size_t)pos * p.m_pad + (size_t)mt_i * WG_BM + wrow0 + lrow) * p.ldm + nt_i * WG_BN + wch0 + lchunk * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 >= p.c_out) continue;
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+            *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoK p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[WG_NS * WG_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int pos, nt_i, mt_i;
+    {   // XCD-aware mapping: the channel tiles of one (position, tile block) are neighbours on one XCD and share V_p through its L2
+        const int nwg = 16 * p.nt * p.mt;
+        const int L = blockIdx.x, xcd = L & 7, q = nwg >> 3, r = nwg & 7;
+        int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        if (p.reverse) w = nwg - 1 - w;
+        nt_i = w % p.nt;
+        const int rest = w / p.nt;
+        mt_i = rest % p.mt;
+        pos = rest / p.mt;
+    }
+    const int wch0 = (wave >> 1) * 64, wrow0 = (wave & 1) * 192;
+    if (wave < 4) gemm_body<T, false>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
+    else          gemm_body<T, true>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
+}
+
+
+// ------------------------------------------------------------------ U = G g G^T, packed [pos][n / 256][c / 32][n % 256][32]
+// G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; f32 arithmetic on the f32 filter, ONE rounding to T.  Rows past c_out and
+// channels past c_in are zero (they meet V's zero padding / are never stored).
+template <typename T>
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, T* __restrict__ u, int c_out, int c_in,
+                                                        int nt, int nsub) {
+    const int ngrp = nsub * 4;                                    // 8-channel groups per row
+    const long long total = (long long)nt * 256 * ngrp;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx / ngrp), cg = (int)(idx - (long long)co * ngrp);
+        float uo[16][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = cg * 8 + e;
+            float g[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) g[k] = (co < c_out && ci < c_in) ? w[((size_t)co * c_in + ci) * 9 + k] : 0.f;
+            float t[4][3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                t[0][kx] = g[kx];
+                t[1][kx] = 0.5f * (g[kx] + g[3 + kx] + g[6 + kx]);
+                t[2][kx] = 0.5f * (g[kx] - g[3 + kx] + g[6 + kx]);
+                t[3][kx] = g[6 + kx];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uo[r * 4 + 0][e] = t[r][0];
+                uo[r * 4 + 1][e] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+                uo[r * 4 + 2][e] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+                uo[r * 4 + 3][e] = t[r][2];
+            }
+        }
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            T* dst = u + ((((size_t)pos * nt + (co >> 8)) * nsub + (cg >> 2)) * 256 + (co & 255)) * 32 + (cg & 3) * 8;
+            *reinterpret_cast<u32x4*>(dst) = pack8(uo[pos], T());
+        }
+    }
+}
+
+// ------------------------------------------------------------------ V = B^T d B
+// One workgroup = one face x 64 channels (two 64-byte sub-steps): the face's padded window of (2 th + 2)^2 pixels - CubePad(1)
+// through cubepad_src(), zeros past it where w is odd - is gathered to LDS once (128 B per pixel), then every (tile, 8-channel
+// chunk) item reads its 4 x 4 window from there and stores its 16 positions.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
+template <typename T>
+__global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, T* __restrict__ v, int w, int th, int c_in,
+                                                      int pix_stride, int nsub, int m_pad, int ncb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
+    const int img = blockIdx.x / ncb, cb = blockIdx.x - img * ncb;
+    const int pw = 2 * th + 2, wp = w + 2;
+    const int cube = img / 6, f = img - cube * 6;
+    const CubePadGeom geom{w, 1, 1, 1, 1};
+    for (int i = threadIdx.x; i < pw * pw * 8; i += 256) {
+        const int pix = i >> 3, ch = i & 7;
+        const int py = pix / pw, px = pix - py * pw;
+        const int c = cb * 64 + ch * 8;
+        u32x4 val = u32x4{0u, 0u, 0u, 0u};
+        if (py < wp && px < wp && c < c_in)
+            val = *reinterpret_cast<const u32x4*>(in + ((size_t)cube * 6 * w * w + cubepad_src(f, py, px, geom)) * pix_stride + c);
+        *reinterpret_cast<u32x4*>(patch + pix * 128 + ch * 16) = val;
+    }
+    __syncthreads();
+    const int tpf = th * th;
+    for (int it = threadIdx.x; it < tpf * 8; it += 256) {
+        const int tile = it >> 3, ch = it & 7;
+        const int sub = cb * 2 + (ch >> 2);
+        if (sub >= nsub) continue;
+        const int ty = tile / th, tx = tile - ty * th;
+        const unsigned char* base = patch + ((2 * ty) * pw + 2 * tx) * 128 + ch * 16;
+        T* dst = v + ((size_t)sub * m_pad + (size_t)img * tpf + tile) * 32 + (ch & 3) * 8;
+        const size_t pstride = (size_t)nsub * m_pad * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                              // row i of V: e[c] = (B^T d)[i][c]
+            const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+            float e[4][8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float da[8], db[8];
+                unpack8(*reinterpret_cast<const u32x4*>(base + (ra * pw + c) * 128), da, T());
+                unpack8(*reinterpret_cast<const u32x4*>(base + (rb * pw + c) * 128), db, T());
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[c][k] = i == 1 ? da[k] + db[k] : da[k] - db[k];
+            }
+            float o[4][8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                o[0][k] = e[0][k] - e[2][k];
+                o[1][k] = e[1][k] + e[2][k];
+                o[2][k] = e[2][k] - e[1][k];
+                o[3][k] = e[1][k] - e[3][k];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(i * 4 + j) * pstride) = pack8(o[j], T());
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Y = A^T M A + bias, A^T = [[1,1,1,0],[0,1,-1,-1]]
+// s[a][j] = sum_i A^T[a][i] M[i][j] column by column, then Y[a][0] = s[a][0] + s[a][1] + s[a][2], Y[a][1] = s[a][1] - s[a][2] - s[a][3].
+template <int NC>      // NC f32 channels per thread (4 or 8): loads NC/4 float4 per position
+__device__ __forceinline__ void out_transform(const float* __restrict__ mp, size_t pstride, float (&y)[4][NC]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) y[q][k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float mm[4][NC];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < NC / 4; ++h) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(mp + (size_t)(i * 4 + j) * pstride + h * 4);
+                mm[i][h * 4 + 0] = t[0]; mm[i][h * 4 + 1] = t[1]; mm[i][h * 4 + 2] = t[2]; mm[i][h * 4 + 3] = t[3];
+            }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const float s0 = mm[0][k] + mm[1][k] + mm[2][k], s1 = mm[1][k] - mm[2][k] - mm[3][k];
+            if (j < 3) { y[0][k] += s0; y[2][k] += s1; }                        // column 0 of Y: + for j = 0, 1, 2
+            if (j == 1) { y[1][k] += s0; y[3][k] += s1; }                       // column 1 of Y: + j = 1, - j = 2, 3
+            if (j >= 2) { y[1][k] -= s0; y[3][k] -= s1; }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+                                                       T* __restrict__ out, int tiles, int w, int th, int c_out, int ldm,
+                                                       int m_pad, int ld_out, int out_coff, int relu) {
+    const int ng = c_out >> 3;
+    const long long total = (long long)tiles * ng;
+    const size_t pstride = (size_t)m_pad * ldm;
+    const int tpf = th * th;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int tg = (int)(idx / ng), c = (int)(idx - (long long)tg * ng) * 8;
+        float y[4][8];
+        out_transform<8>(m + (size_t)tg * ldm + c, pstride, y);
+        float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
+            b[0] = b0[0]; b[1] = b0[1]; b[2] = b0[2]; b[3] = b0[3]; b[4] = b1[0]; b[5] = b1[1]; b[6] = b1[2]; b[7] = b1[3];
+        }
+        const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
+            if (oy >= w || ox >= w) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                y[q][k] += b[k];
+                if (relu) y[q][k] = fmaxf(y[q][k], 0.f);
+            }
+            *reinterpret_cast<u32x4*>(out + ((size_t)(img * w + oy) * w + ox) * ld_out + out_coff + c) = pack8(y[q], T());
+        }
+    }
+}
+
+// The Gates convolution's output transform + the cell update of model/clstm.py:68-80 (gate order in, remember, out, cell),
+// with the optional window normalisation of the NEXT frame into the x half (as lstm_gates_kernel, conv_igemm.hip).
+__device__ __forceinline__ float wsigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void wino_gates_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+                                                         const float* __restrict__ c_prev, float* __restrict__ c_next,
+                                                         T* __restrict__ h_out, int ld_h, int h_coff, float* __restrict__ h_f32,
+                                                         int tiles, int w, int th, int Hc, int ldm, int m_pad,
+                                                         const float* __restrict__ x_next, const float* __restrict__ minmax,
+                                                         int x_coff, size_t clip_stride) {
+    const int ng = Hc >> 2;
+    const long long total = (long long)tiles * ng;
+    const size_t pstride = (size_t)m_pad * ldm;
+    const int tpf = th * th, P = 6 * w * w;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int tg = (int)(idx / ng), j = (int)(idx - (long long)tg * ng) * 4;
+        float g[4][4][4];                                          // [gate][pixel of the tile][channel]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            out_transform<4>(m + (size_t)tg * ldm + k * Hc + j, pstride, g[k]);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + k * Hc + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { g[k][q][0] += bb[0]; g[k][q][1] += bb[1]; g[k][q][2] += bb[2]; g[k][q][3] += bb[3]; }
+        }
+        const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
+            if (oy >= w || ox >= w) continue;
+            const size_t mpx = (size_t)(img * w + oy) * w + ox;
+            const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + mpx * Hc + j);
+            float cn[4], hn[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ig = wsigmoid(g[0][q][e]), fg = wsigmoid(g[1][q][e]), og = wsigmoid(g[2][q][e]);
+                const float cg = tanhf(g[3][q][e]);
+                cn[e] = fg * cp[e] + ig * cg;
+                hn[e] = og * tanhf(cn[e]);
+            }
+            *reinterpret_cast<f32x4*>(c_next + mpx * Hc + j) = f32x4{cn[0], cn[1], cn[2], cn[3]};
+            store4(h_out + mpx * ld_h + h_coff + j, hn);
+            if (h_f32) *reinterpret_cast<f32x4*>(h_f32 + mpx * Hc + j) = f32x4{hn[0], hn[1], hn[2], hn[3]};
+            if (x_next) {
+                const int b = (int)(mpx / P), pix = (int)(mpx - (size_t)b * P);
+                const float mn = minmax[2 * b], den = minmax[2 * b + 1] - mn;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x_next + (size_t)b * clip_stride + (size_t)pix * Hc + j);
+                const float xn[4] = {(xv[0] - mn) / den, (xv[1] - mn) / den, (xv[2] - mn) / den, (xv[3] - mn) / den};
+                store4(h_out + mpx * ld_h + x_coff + j, xn);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+namespace {
+struct WinoGeom { int th, tpf, tiles, mt, m_pad, nsub, nt, ldm; };
+
+int wino_check(const cp360_wino_desc* d, WinoGeom* g) {
+    if (!d) return CP360_ERR_NULL;
+    if (d->dtype != CP360_BF16 && d->dtype != CP360_F16) return CP360_ERR_BAD_DTYPE;
+    if (d->n_img <= 0 || d->face < 2 || d->c_in <= 0 || d->c_out <= 0 || d->pix_stride < d->c_in) return CP360_ERR_BAD_SHAPE;
+    if (d->n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+    if (d->c_in % 8 != 0 || d->c_out % 8 != 0 || d->pix_stride % 8 != 0 || d->ld_out % 8 != 0 || d->out_coff % 8 != 0) return CP360_ERR_ALIGN;
+    if (d->ld_out != 0 && d->ld_out < d->c_out + d->out_coff) return CP360_ERR_BAD_SHAPE;
+    if ((long long)d->n_img * d->face * d->face * d->pix_stride >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    g->th = (d->face + 1) / 2;
+    g->tpf = g->th * g->th;
+    g->tiles = d->n_img * g->tpf;
+    g->mt = (g->tiles + WG_BM - 1) / WG_BM;
+    g->m_pad = g->mt * WG_BM;
+    g->nsub = (d->c_in + 31) / 32;
+    g->nt = (d->c_out + WG_BN - 1) / WG_BN;
+    g->ldm = d->c_out;
+    return CP360_OK;
+}
+}  // namespace
+
+extern "C" size_t cp360_wino_packed_bytes(const cp360_wino_desc* d) {
+    WinoGeom g;
+    return wino_check(d, &g) ? 0 : (size_t)16 * g.nt * g.nsub * WG_BN * 64;
+}
+extern "C" size_t cp360_wino_v_bytes(const cp360_wino_desc* d) {
+    WinoGeom g;
+    return wino_check(d, &g) ? 0 : (size_t)16 * g.nsub * g.m_pad * 64;
+}
+extern "C" size_t cp360_wino_m_bytes(const cp360_wino_desc* d) {
+    WinoGeom g;
+    return wino_check(d, &g) ? 0 : (size_t)16 * g.m_pad * g.ldm * sizeof(float);
+}
+
+// 1: the planner would run this CubePad(1) + 3x3 convolution in the Winograd domain: 16-bit type, and its 16 GEMMs over the padded
+// tile count need at most 0.8 of the direct form's MFMAs (4 clips of 7x7 faces: 0.58; one clip of 16x16 faces: 0.44; one clip of
+// 7x7 faces: 1.8 - the direct clip-resident kernel stays).  CP360_WINO=0 / 1 forces never / whenever supported.
+extern "C" int cp360_wino_preferred(const cp360_wino_desc* d) {
+    WinoGeom g;
+    if (wino_check(d, &g)) return 0;
+    static const int env = []() { const char* e = getenv("CP360_WINO"); return e ? atoi(e) : -1; }();
+    if (env == 0) return 0;
+    if (env == 1) return 1;
+    if (d->c_out < 1024 || d->c_in < 256) return 0;
+    return 16.0 * g.m_pad <= 0.8 * 9.0 * d->n_img * d->face * d->face ? 1 : 0;
+}
+
+extern "C" int cp360_wino_pack_weights(const cp360_wino_desc* d, const float* w_oihw, void* packed, void* stream) {
+    WinoGeom g;
+    int rc = wino_check(d, &g);
+    if (rc) return rc;
+    if (!w_oihw || !packed) return CP360_ERR_NULL;
+    const long long total = (long long)g.nt * 256 * g.nsub * 4;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((wino_pack_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, (f16_raw*)packed, d->c_out, d->c_in, g.nt, g.nsub);
+    else
+        hipLaunchKernelGGL((wino_pack_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, w_oihw, (bf16_raw*)packed, d->c_out, d->c_in, g.nt, g.nsub);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_wino_input(const cp360_wino_desc* d, const void* in, void* v, void* stream) {
+    WinoGeom g;
+    int rc = wino_check(d, &g);
+    if (rc) return rc;
+    if (!in || !v) return CP360_ERR_NULL;
+    const int ncb = (g.nsub + 1) / 2, pw = 2 * g.th + 2;
+    const size_t lds = (size_t)pw * pw * 128;
+    if (lds > 64 * 1024) return CP360_ERR_UNSUPPORTED;                 // faces up to 42 x 42
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(d->n_img * ncb));
+    if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((wino_in_kernel<f16_raw>), grid, dim3(256), lds, st, (const f16_raw*)in, (f16_raw*)v, d->face, g.th, d->c_in,
+                           d->pix_stride, g.nsub, g.m_pad, ncb);
+    else
+        hipLaunchKernelGGL((wino_in_kernel<bf16_raw>), grid, dim3(256), lds, st, (const bf16_raw*)in, (bf16_raw*)v, d->face, g.th, d->c_in,
+                           d->pix_stride, g.nsub, g.m_pad, ncb);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_wino_gemm(const cp360_wino_desc* d, const void* v, const void* packed, float* m, void* stream) {
+    WinoGeom g;
+    int rc = wino_check(d, &g);
+    if (rc) return rc;
+    if (!v || !packed || !m) return CP360_ERR_NULL;
+    WinoK k;
+    k.u = (const unsigned char*)packed; k.v = (const unsigned char*)v; k.m = m;
+    k.nsub = g.nsub; k.nt = g.nt; k.mt = g.mt; k.m_pad = g.m_pad; k.ldm = g.ldm; k.c_out = d->c_out;
+    k.reverse = cp360_launch_reverse();
+    dim3 grid((unsigned)(16 * g.nt * g.mt));
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CP360_F16) hipLaunchKernelGGL((wino_gemm_kernel<f16_raw>), grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((wino_gemm_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_wino_output(const cp360_wino_desc* d, const float* m, const float* bias, void* out, void* stream) {
+    WinoGeom g;
+    int rc = wino_check(d, &g);
+    if (rc) return rc;
+    if (!m || !out) return CP360_ERR_NULL;
+    const int ld_out = d->ld_out ? d->ld_out : d->c_out;
+    const long long total = (long long)g.tiles * (d->c_out / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((wino_out_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (f16_raw*)out, g.tiles, d->face, g.th,
+                           d->c_out, g.ldm, g.m_pad, ld_out, d->out_coff, d->relu);
+    else
+        hipLaunchKernelGGL((wino_out_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (bf16_raw*)out, g.tiles, d->face, g.th,
+                           d->c_out, g.ldm, g.m_pad, ld_out, d->out_coff, d->relu);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+extern "C" int cp360_wino_output_gates(const cp360_wino_desc* d, const float* m, const float* bias, const float* c_prev, float* c_next,
+                                       void* h_out, int ld_h, int h_coff, float* h_f32, const float* x_next, const float* minmax,
+                                       int x_coff, size_t clip_stride, void* stream) {
+    WinoGeom g;
+    int rc = wino_check(d, &g);
+    if (rc) return rc;
+    if (!m || !bias || !c_prev || !c_next || !h_out) return CP360_ERR_NULL;
+    if (d->c_out % 16 != 0) return CP360_ERR_ALIGN;
+    const int Hc = d->c_out / 4;
+    if (ld_h % 4 != 0 || h_coff % 4 != 0 || h_coff + Hc > ld_h) return CP360_ERR_BAD_SHAPE;
+    if (x_next && (!minmax || x_coff % 4 != 0 || clip_stride % 4 != 0 || x_coff + Hc > ld_h || (x_coff < h_coff + Hc && h_coff < x_coff + Hc)))
+        return CP360_ERR_BAD_SHAPE;
+    const long long total = (long long)g.tiles * (Hc / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((wino_gates_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (f16_raw*)h_out, ld_h,
+                           h_coff, h_f32, g.tiles, d->face, g.th, Hc, g.ldm, g.m_pad, x_next, minmax, x_coff, clip_stride);
+    else
+        hipLaunchKernelGGL((wino_gates_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h,
+                           h_coff, h_f32, g.tiles, d->face, g.th, Hc, g.ldm, g.m_pad, x_next, minmax, x_coff, clip_stride);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+// in -> V -> M -> out: the whole convolution (v / m: workspaces of cp360_wino_v_bytes / cp360_wino_m_bytes)
+extern "C" int cp360_wino_forward(const cp360_wino_desc* d, const void* in, const void* packed, const float* bias, void* out, void* v,
+                                  float* m, void* stream) {
+    int rc;
+    if ((rc = cp360_wino_input(d, in, v, stream))) return rc;
+    if ((rc = cp360_wino_gemm(d, v, packed, m, stream))) return rc;
+    return cp360_wino_output(d, m, bias, out, stream);
+}
+
+// the bare GEMM on caller-made operands (tools/wino_probe.py)
+extern "C" int cp360_wino_gemm_raw(int dtype, const void* u, const void* v, float* m, int nsub, int nt, int mt, int ldm,
+                                   int c_out, void* stream) {
+    if (!u || !v || !m) return CP360_ERR_NULL;
+    if (dtype != CP360_BF16 && dtype != CP360_F16) return CP360_ERR_BAD_DTYPE;
+    if (nsub < 1 || nt < 1 || mt < 1 || ldm % 4 != 0 || c_out % 4 != 0 || c_out > nt * WG_BN || ldm < c_out) return CP360_ERR_BAD_SHAPE;
+    WinoK k;
+    k.u = (const unsigned char*)u; k.v = (const unsigned char*)v; k.m = m;
+    k.nsub = nsub; k.nt = nt; k.mt = mt; k.m_pad = mt * WG_BM; k.ldm = ldm; k.c_out = c_out;
+    k.reverse = cp360_launch_reverse();
+    dim3 grid((unsigned)(16 * nt * mt));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CP360_F16) hipLaunchKernelGGL((wino_gemm_kernel<f16_raw>), grid, dim3(512), 0, st, k);
+    else hipLaunchKernelGGL((wino_gemm_kernel<bf16_raw>), grid, dim3(512), 0, st, k);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}

@@ -743,6 +743,116 @@ def lstm_gates(partial, splits, bias, c_prev, c_next, h_out, h_coff, h_f32, M, H
                                  int(slab_rows), stream()))
 
 
+class WinoConv:
+    """CubePad(1) + 3x3 convolution in the Winograd F(2x2, 3x3) domain (csrc/wino.hip, include/cp360.h "K5w"): the 16-bit
+    form of the ConvLSTM convolutions (model/clstm.py:56-64) when the launch has enough tiles to fill 384-row GEMM tiles.
+    weight f32 [c_out, c_in, 3, 3], bias f32 [c_out] or None.  ``preferred(n_img, face)`` = the library's planner."""
+
+    # one V / M workspace pair per (device, dtype), shared by every convolution of the cell: V is dead once the GEMM has
+    # run and M once its output transform has (stream order)
+    _ws = {}
+
+    def __init__(self, weight, bias=None, relu=False, dtype=torch.bfloat16, device='cuda'):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("the Winograd path runs in bf16 / fp16 (f32 stays on the direct kernels)")
+        if tuple(weight.shape[2:]) != (3, 3):
+            raise ValueError("a [c_out, c_in, 3, 3] filter")
+        self.dtype, self.device, self.relu = dtype, torch.device(device), bool(relu)
+        self.c_out, self.c_in = int(weight.shape[0]), int(weight.shape[1])
+        self._w_src = weight.detach()
+        self.bias = None if bias is None else bias.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._packed = None
+        self.tag = 'wino'
+
+    def desc(self, n_img, face, pix_stride=None, ld_out=0, out_coff=0, relu=None):
+        d = _lib.WinoDesc()
+        d.dtype = dtype_code(self.dtype)
+        d.n_img, d.face, d.c_in, d.c_out = n_img, face, self.c_in, self.c_out
+        d.pix_stride = self.c_in if pix_stride is None else pix_stride
+        d.ld_out, d.out_coff = ld_out, out_coff
+        d.relu = int(self.relu if relu is None else relu)
+        return d
+
+    def preferred(self, n_img, face):
+        return bool(lib().cp360_wino_preferred(C.byref(self.desc(n_img, face))))
+
+    @property
+    def packed(self):
+        if self._packed is None:
+            d = self.desc(6, 8)
+            w = self._w_src.to(device=self.device, dtype=torch.float32).contiguous()
+            t = torch.empty(lib().cp360_wino_packed_bytes(C.byref(d)), dtype=torch.uint8, device=self.device)
+            check(lib().cp360_wino_pack_weights(C.byref(d), ptr(w), ptr(t), stream()))
+            self._packed = t
+        return self._packed
+
+    def workspace(self, d):
+        key = (self.device, self.dtype)
+        need_v, need_m = lib().cp360_wino_v_bytes(C.byref(d)), lib().cp360_wino_m_bytes(C.byref(d))
+        v, m = WinoConv._ws.get(key, (None, None))
+        if v is None or v.numel() < need_v:
+            v = torch.empty(need_v, dtype=torch.uint8, device=self.device)
+        if m is None or m.numel() * 4 < need_m:
+            m = torch.empty(need_m // 4, dtype=torch.float32, device=self.device)
+        WinoConv._ws[key] = (v, m)
+        return v, m
+
+    def _check_in(self, x):
+        require_gpu(x)
+        if x.dim() != 4 or x.dtype != self.dtype or not x.is_contiguous() or x.shape[1] != x.shape[2] or x.shape[3] < self.c_in \
+                or x.shape[0] % 6:
+            raise ValueError("x must be a contiguous %s [6B, w, w, >= %d] tensor" % (self.dtype, self.c_in))
+
+    def sums(self, x):
+        """Input transform + the 16 GEMMs: returns (M workspace f32 [16, m_pad, c_out], desc) for an output transform."""
+        self._check_in(x)
+        n_img, w = x.shape[0], x.shape[1]
+        d = self.desc(n_img, w, pix_stride=x.shape[3])
+        v, m = self.workspace(d)
+        L = lib()
+        check(L.cp360_wino_input(C.byref(d), ptr(x), ptr(v), stream()))
+        if LAUNCH_TIMER is None:
+            check(L.cp360_wino_gemm(C.byref(d), ptr(v), ptr(self.packed), ptr(m), stream()))
+        else:
+            flops = 2.0 * n_img * w * w * self.c_out * self.c_in * 9          # quoted on the DIRECT form's flops
+            packed = self.packed
+            check(LAUNCH_TIMER.wrap(self.tag, flops, lambda: L.cp360_wino_gemm(C.byref(d), ptr(v), ptr(packed), ptr(m), stream())))
+        return m, d
+
+    def __call__(self, x, out=None, out_coff=0):
+        m, d = self.sums(x)
+        n_img, w = x.shape[0], x.shape[1]
+        if out is None:
+            out = torch.empty((n_img, w, w, self.c_out), dtype=self.dtype, device=x.device)
+        require_gpu(out)
+        _check_buf('out', out, self.dtype, (n_img, w, w, self.c_out + out_coff))
+        d.ld_out, d.out_coff = out.shape[3], out_coff
+        check(lib().cp360_wino_output(C.byref(d), ptr(m), ptr(self.bias), ptr(out), stream()))
+        return out
+
+    def gates(self, x, bias, c_prev, c_next, h_out, h_coff, h_f32=None, x_next=None):
+        """The Gates convolution + the cell update (clstm.py:68-80) in the output transform; x_next as ops.lstm_gates."""
+        m, d = self.sums(x)
+        n_img, w = x.shape[0], x.shape[1]
+        M, Hc = n_img * w * w, self.c_out // 4
+        require_gpu(bias, c_prev, c_next, h_out, h_f32)
+        _check_buf('gates bias', bias, torch.float32, numel=4 * Hc)
+        _check_buf('c_prev', c_prev, torch.float32, numel=M * Hc)
+        _check_buf('c_next', c_next, torch.float32, numel=M * Hc)
+        _check_buf('h_f32', h_f32, torch.float32, numel=M * Hc)
+        if h_out.dtype != self.dtype or not h_out.is_contiguous() or h_out.numel() < M * h_out.shape[-1] or h_coff + Hc > h_out.shape[-1]:
+            raise ValueError("h_out must be a contiguous %s [.., ld] tensor with M pixels and h_coff + Hc <= ld" % self.dtype)
+        xp, mm, x_coff, stride = None, None, 0, 0
+        if x_next is not None:
+            cam, minmax, x_coff, P, stride, t_next = x_next
+            require_gpu(cam, minmax)
+            _check_buf('cam', cam, torch.float32, numel=(M // P - 1) * stride + (t_next + 1) * P * Hc)
+            _check_buf('minmax', minmax, torch.float32, numel=2 * (M // P))
+            xp, mm = C.c_void_p(cam.data_ptr() + 4 * t_next * P * Hc), ptr(minmax)
+        check(lib().cp360_wino_output_gates(C.byref(d), ptr(m), ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out), h_out.shape[-1],
+                                            h_coff, ptr(h_f32), xp, mm, x_coff, stride, stream()))
+
+
 def window_minmax(x, B, per_clip, minmax, scratch, clip_stride=0):
     require_gpu(x, minmax, scratch)
     _check_buf('x', x, torch.float32, numel=(B - 1) * (clip_stride or per_clip) + per_clip)

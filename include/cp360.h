@@ -53,7 +53,7 @@ const char* cp360_strerror(int status);
 /* library / ABI version: major*10000 + minor*100 + patch.  Bumped on EVERY change of a struct, a
  * signature or a packed-weight layout: the binding (_lib.py: ABI_VERSION) refuses a library whose
  * version or sizeof(cp360_conv_desc) differs, so a stale out-of-band .so fails at load time. */
-#define CP360_VERSION 304
+#define CP360_VERSION 305
 int cp360_version(void);
 /* sizeof(cp360_conv_desc) as the library was compiled. */
 size_t cp360_conv_desc_bytes(void);
@@ -279,6 +279,46 @@ int cp360_lstm_gates_next(const float* gates_partial, int splits, const float* b
                           int ld_h, int h_coff, float* h_f32, int M, int Hc, int slab_rows,
                           const float* x_next, const float* minmax, int x_coff, int P, size_t clip_stride,
                           void* stream);
+
+/* ------------------------------------------------------------------ K5w: CubePad(1) + 3x3 convolution in the Winograd domain
+ * The three ConvLSTM convolutions of model/clstm.py:56-64 as F(2x2, 3x3) for the 16-bit types: a w x w face is cut into
+ * th x th tiles of 2 x 2 outputs (th = ceil(w / 2)); U = G g G^T is packed once per filter (16 matrices [c_out, c_in]), the
+ * input transform V = B^T d B reads the cube-padded 4 x 4 window behind every tile, sixteen f32-accumulated MFMA GEMMs
+ * M_p = V_p U_p^T (256 channels x 384 tiles per workgroup, both operands streamed) replace the 9-tap implicit GEMM, and
+ * Y = A^T M A (+ bias, ReLU - or the LSTM gate update) writes the activations: 16 / 36 of the direct form's multiplies at even
+ * face sizes, 256 / 441 at 7x7.  U and V are rounded once to the 16-bit type, every sum is f32.  f32 convolutions stay on
+ * cp360_conv_forward (exact f32 MFMA, the 1e-3 parity path).
+ *   in   [n_img, w, w, pix_stride] (the first c_in channels of a pixel), n_img = 6 * cubes
+ *   v    workspace of cp360_wino_v_bytes: [16][ceil(c_in / 32)][m_pad][32] (m_pad = tiles rounded up to 384)
+ *   m    workspace of cp360_wino_m_bytes: f32 [16][m_pad][c_out]
+ *   out  [n_img, w, w, ld_out] at channel out_coff (ld_out 0 = c_out) */
+typedef struct {
+    int dtype;        /* CP360_BF16 or CP360_F16                                   */
+    int n_img;        /* faces (6 * cubes)                                         */
+    int face;         /* w: faces are w x w                                        */
+    int c_in;         /* % 8 == 0                                                  */
+    int pix_stride;   /* elements between neighbouring input pixels (>= c_in)      */
+    int c_out;        /* % 8 == 0 (% 16 for the gate epilogue)                     */
+    int ld_out, out_coff, relu;
+} cp360_wino_desc;
+size_t cp360_wino_packed_bytes(const cp360_wino_desc* d);
+size_t cp360_wino_v_bytes(const cp360_wino_desc* d);
+size_t cp360_wino_m_bytes(const cp360_wino_desc* d);
+/* 1: the library's planner runs this geometry in the Winograd domain (16-bit type and at most 0.8 of the direct form's MFMAs
+ * after padding the tile count to 384: 4 clips of 7x7 faces, one clip of 16x16 faces, ...), 0: on the direct kernels. */
+int cp360_wino_preferred(const cp360_wino_desc* d);
+int cp360_wino_pack_weights(const cp360_wino_desc* d, const float* w_oihw /* f32 [c_out, c_in, 3, 3] */, void* packed, void* stream);
+int cp360_wino_input(const cp360_wino_desc* d, const void* in, void* v, void* stream);
+int cp360_wino_gemm(const cp360_wino_desc* d, const void* v, const void* packed, float* m, void* stream);
+int cp360_wino_output(const cp360_wino_desc* d, const float* m, const float* bias, void* out, void* stream);
+/* Output transform of the Gates convolution + cp360_lstm_gates_next's update in one pass (gate g of hidden channel j is
+ * convolution channel g * Hc + j, Hc = c_out / 4; bias f32 [c_out]); arguments as cp360_lstm_gates_next, h_out in d->dtype. */
+int cp360_wino_output_gates(const cp360_wino_desc* d, const float* m, const float* bias, const float* c_prev, float* c_next,
+                            void* h_out, int ld_h, int h_coff, float* h_f32, const float* x_next, const float* minmax,
+                            int x_coff, size_t clip_stride, void* stream);
+/* cp360_wino_input + cp360_wino_gemm + cp360_wino_output. */
+int cp360_wino_forward(const cp360_wino_desc* d, const void* in, const void* packed, const float* bias, void* out, void* v,
+                       float* m, void* stream);
 
 /* ------------------------------------------------------------------ K7: window normalise
  * temporal_model/test_temporal.py:66-67,70-73,77: per clip min / max over the whole

@@ -147,6 +147,12 @@ int cp360_l3block_forward(int dtype, const void* mid, const void* w2_packed, con
  * and its consumer lets the consumer begin with the resident lines.  Returns the previous setting. */
 int cp360_set_launch_order(int mode);
 
+/* ------------------------------------------------------------------ the bare Winograd-domain GEMM (tools/wino_probe.py)
+ * m[pos][tile][c] = sum_k v[pos][k / 32][tile][k % 32] * u[pos][c / 256][k / 32][c % 256][k % 32] on caller-made operands:
+ * 16 positions x nt channel tiles x mt tile blocks of 384, nsub 64-byte K sub-steps. */
+int cp360_wino_gemm_raw(int dtype, const void* u, const void* v, float* m, int nsub, int nt, int mt, int ldm, int c_out,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

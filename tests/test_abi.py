@@ -27,8 +27,8 @@ def test_library_exports_every_header_symbol():
     # the documented boundary (cp360.h) and the internal fused-kernel entry points (cp360_internal.h) are bound separately
     assert declared == set(_lib.PUBLIC_SYMBOLS)
     assert declared_internal == set(_lib.INTERNAL_SYMBOLS)
-    # the internal ones are exactly the shape-specific kernels + the launch-order hint: nothing a binder of the reference needs
-    assert all(re.match(r'cp360_(stem|band3x3|frag|l1block|l2block|l2first|l3block|set_launch_order)', n) for n in declared_internal)
+    # the internal ones are exactly the shape-specific kernels + the launch-order hint + the bare GEMM of tools/wino_probe.py: nothing a binder of the reference needs
+    assert all(re.match(r'cp360_(stem|band3x3|frag|l1block|l2block|l2first|l3block|set_launch_order|wino_gemm_raw)', n) for n in declared_internal)
     hv = int(re.search(r'#define\s+CP360_VERSION\s+(\d+)', hdr).group(1))
     assert L.cp360_version() == hv == _lib.ABI_VERSION           # header, library and binding agree
     assert L.cp360_conv_desc_bytes() == C.sizeof(_lib.ConvDesc)

@@ -1,0 +1,140 @@
+"""The Winograd F(2x2, 3x3) form of CubePad(1) + 3x3 convolution (csrc/wino.hip, include/cp360.h "K5w") - the 16-bit ConvLSTM
+convolutions of /root/reference/model/clstm.py:56-64 - through the C ABI against torch-CPU on the oracle's CubePad:
+pack (U = G g G^T), input transform, the 16 GEMMs, output transform (+ bias, ReLU) and the gate epilogue (clstm.py:68-80).
+
+Tolerances: U and V are rounded once to the 16-bit type on top of the direct form's operand rounding; the bound is still the
+direct kernels' (tests/test_gpu_parity.py _TOL), plus an RMS bound that a wrong tile / position would break at once.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from oracle import o_resnet
+from cp_360_weakly_supervised_saliency_amd import _lib, ops
+from cp_360_weakly_supervised_saliency_amd.utils import hashrng
+
+DEV = 'cuda'
+_TDT = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+_TOL = {'bf16': 1.2e-2, 'fp16': 1.5e-3}        # max |d| / max |want|: the direct kernels' bound (measured 5e-3 / 7e-4)
+_RMS = {'bf16': 7e-3, 'fp16': 9e-4}            # rms(d) / rms(want) (measured 4.6e-3 / 5.7e-4)
+
+
+def _rb(a, dt):
+    return torch.from_numpy(a).to(dt).float()
+
+
+def _ref(x, w, bias, dt, relu):
+    y = Fn.conv2d(o_resnet.cubepad_t(_rb(x, dt), 1), _rb(w, dt), torch.from_numpy(bias))
+    return (Fn.relu(y) if relu else y).numpy()
+
+
+def _errs(got, want):
+    d = got - want
+    return float(np.max(np.abs(d)) / np.max(np.abs(want))), float(np.sqrt(np.mean(d * d)) / np.sqrt(np.mean(want * want)))
+
+
+# ------------------------------------------------------------------ host-side planner and sizes (no GPU)
+def test_wino_planner_and_sizes():
+    L = _lib.lib()
+    d = _lib.WinoDesc()
+    d.dtype, d.c_in, d.pix_stride, d.c_out = _lib.BF16, 4000, 4000, 4000
+    want = {(6, 7): 0, (12, 7): 0, (18, 7): 1, (24, 7): 1, (30, 7): 0, (48, 7): 1, (6, 16): 1, (6, 8): 0, (24, 8): 1}
+    import os
+    if os.environ.get('CP360_WINO') is None:
+        for (n, f), p in want.items():
+            d.n_img, d.face = n, f
+            assert L.cp360_wino_preferred(C.byref(d)) == p, (n, f)
+    d.n_img, d.face = 24, 7
+    assert L.cp360_wino_packed_bytes(C.byref(d)) == 16 * 16 * 125 * 256 * 64          # 16 positions x 16 channel tiles x 125 sub-steps
+    assert L.cp360_wino_v_bytes(C.byref(d)) == 16 * 125 * 384 * 64
+    assert L.cp360_wino_m_bytes(C.byref(d)) == 16 * 384 * 4000 * 4
+    d.n_img = 30                                                                       # 480 tiles: two 384-row blocks
+    assert L.cp360_wino_v_bytes(C.byref(d)) == 16 * 125 * 768 * 64
+    # errors: f32, n_img not 6n, misaligned channels
+    d.dtype = _lib.F32
+    assert L.cp360_wino_packed_bytes(C.byref(d)) == 0 and L.cp360_wino_preferred(C.byref(d)) == 0
+    d.dtype, d.n_img = _lib.BF16, 7
+    assert L.cp360_wino_gemm(C.byref(d), None, None, None, None) == -2
+    d.n_img, d.c_in = 6, 12
+    assert L.cp360_wino_gemm(C.byref(d), None, None, None, None) == -6
+
+
+# ------------------------------------------------------------------ the convolution
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n,n_img', [(7, 24), (7, 30), (8, 12), (16, 6), (5, 6), (4, 12), (3, 6), (2, 6)])
+def test_wino_conv_matches_torch_cpu(n, n_img, prec):
+    """c_in = 104: the K tail ends inside a 64-byte sub-step; c_out = 264: a ragged second channel tile; 30 faces of 7x7 = 480
+    tiles: two 384-row tile blocks, the second ragged; odd faces: the last tile row / column hangs over the face."""
+    dt = _TDT[prec]
+    cin, cout = 104, 264
+    x = hashrng.normal(7400 + n, (n_img, cin, n, n))
+    w = hashrng.normal(7401, (cout, cin, 3, 3), 0, (2.0 / (9 * cin)) ** 0.5)
+    bias = hashrng.normal(7403, (cout,), 0, 0.1)
+    want = _ref(x, w, bias, dt, True)
+    conv = ops.WinoConv(torch.from_numpy(w), torch.from_numpy(bias), True, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    got = ops.nhwc_to_nchw(conv(xt), out_dtype=torch.float32).cpu().numpy()
+    mx, rms = _errs(got, want)
+    print('wino %s n=%d n_img=%d: max %.2e rms %.2e' % (prec, n, n_img, mx, rms))
+    assert mx <= _TOL[prec] and rms <= _RMS[prec], (mx, rms)
+
+
+@pytest.mark.gpu
+def test_wino_conv_strided_pixels_and_output_offset():
+    """The ConvLSTM's layouts: the input is the first c_in channels of a wider pixel (the fused [x | h] buffer), the output goes
+    to a channel offset of a wider pixel; no ReLU, no bias."""
+    dt = torch.bfloat16
+    n, n_img, cin, cout, ld_in, ld_out, coff = 7, 24, 96, 256, 160, 320, 40
+    x = hashrng.normal(7500, (n_img, ld_in, n, n))
+    w = hashrng.normal(7501, (cout, cin, 3, 3), 0, (2.0 / (9 * cin)) ** 0.5)
+    want = _ref(x[:, :cin], w, np.zeros(cout, np.float32), dt, False)
+    conv = ops.WinoConv(torch.from_numpy(w), None, False, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    out = torch.full((n_img, n, n, ld_out), 7.0, dtype=dt, device=DEV)
+    conv(xt, out=out, out_coff=coff)
+    o = out.float().cpu().numpy()
+    assert np.all(o[..., :coff] == 7.0) and np.all(o[..., coff + cout:] == 7.0)      # nothing outside its channels
+    got = o[..., coff:coff + cout].transpose(0, 3, 1, 2)
+    mx, rms = _errs(got, want)
+    assert mx <= _TOL['bf16'] and rms <= _RMS['bf16'], (mx, rms)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n', [7, 16])
+def test_wino_gates_matches_torch_cpu(n, prec):
+    """Gates convolution + cell update in the output transform (clstm.py:68-80) with the next frame's window normalisation
+    written into the x half, against torch-CPU gate arithmetic on the torch-CPU convolution of the same rounded operands."""
+    dt = _TDT[prec]
+    B, Hc, cin = (4 if n == 7 else 1), 16, 64
+    n_img, P, M = 6 * B, 6 * n * n, 6 * B * n * n
+    a2 = hashrng.normal(7600 + n, (n_img, cin, n, n))
+    w = hashrng.normal(7601, (4 * Hc, cin, 3, 3), 0, (2.0 / (9 * cin)) ** 0.5)
+    bias = hashrng.normal(7602, (4 * Hc,), 0, 0.2)
+    cprev = hashrng.normal(7603, (n_img, Hc, n, n))
+    cam = hashrng.normal(7604, (B, 2, P, Hc), 5.0, 2.0)                     # two frames per clip, pixel-major
+    mm = np.stack([cam.reshape(B, -1).min(1), cam.reshape(B, -1).max(1)], 1).astype(np.float32)
+    g = _ref(a2, w, bias, dt, False)
+    i_g, f_g, o_g, c_g = [torch.from_numpy(t) for t in np.split(g, 4, 1)]
+    cn = torch.sigmoid(f_g) * torch.from_numpy(cprev) + torch.sigmoid(i_g) * torch.tanh(c_g)
+    hn = torch.sigmoid(o_g) * torch.tanh(cn)
+    conv = ops.WinoConv(torch.from_numpy(w), None, False, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(a2).to(DEV), out_dtype=dt)
+    cp = ops.nchw_to_nhwc(torch.from_numpy(cprev).to(DEV))
+    c_next = torch.empty_like(cp)
+    h_f32 = torch.empty_like(cp)
+    xh = torch.zeros((n_img, n, n, 2 * Hc), dtype=dt, device=DEV)
+    camt, mmt = torch.from_numpy(cam).to(DEV), torch.from_numpy(mm).to(DEV)
+    conv.gates(xt, torch.from_numpy(bias).to(DEV), cp, c_next, xh, Hc, h_f32, x_next=(camt, mmt, 0, P, 2 * P * Hc, 1))
+    got_c = ops.nhwc_to_nchw(c_next).cpu().numpy()
+    got_h = ops.nhwc_to_nchw(h_f32).cpu().numpy()
+    tol = 2.5e-2 if prec == 'bf16' else 3e-3
+    assert np.max(np.abs(got_c - cn.numpy())) <= tol and np.max(np.abs(got_h - hn.numpy())) <= tol
+    xhc = xh.float().cpu().numpy()
+    assert np.max(np.abs(xhc[..., Hc:].transpose(0, 3, 1, 2) - got_h)) <= (8e-3 if prec == 'bf16' else 1e-3)   # h half = rounded h
+    xn = (cam[:, 1] - mm[:, :1, None]) / (mm[:, 1:, None] - mm[:, :1, None])                                    # [B, P, Hc]
+    assert np.max(np.abs(xhc[..., :Hc].reshape(B, P, Hc) - xn)) <= (4e-3 if prec == 'bf16' else 5e-4)
