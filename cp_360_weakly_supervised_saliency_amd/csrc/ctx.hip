@@ -246,7 +246,25 @@ struct CClstm {
     CConv c1x, c1h;                              // Conv1 split into its x / h input halves (cp360_clstm_window, batched x half)
     bool split_ok = false;
     float* gbias = nullptr;
+    // Winograd-domain filters U = G g G^T of the three convolutions (cp360_clstm_load_wino; csrc/wino.hip), 16-bit types
+    void *u1 = nullptr, *u2 = nullptr, *ug = nullptr;
+    bool wino_loaded = false;
 };
+
+// the Winograd descriptors of a cell update on n6 faces of face x face
+void wino_descs(const CClstm& Cl, int n6, int face, cp360_wino_desc* d1, cp360_wino_desc* d2, cp360_wino_desc* dg) {
+    const int c4 = 4 * Cl.ch, cx = Cl.cin + Cl.ch;
+    *d1 = cp360_wino_desc{Cl.dtype, n6, face, cx, cx, c4, c4, 0, 1};
+    *d2 = cp360_wino_desc{Cl.dtype, n6, face, c4, c4, c4, c4, 0, 1};
+    *dg = cp360_wino_desc{Cl.dtype, n6, face, c4, c4, c4, c4, 0, 0};
+}
+// the library's rule, on Conv2's shape (the same test as ConvLSTMCell.uses_winograd of the CP360_CTX=0 path)
+bool wino_wanted(const CClstm& Cl, int n_clips, int face) {
+    if (Cl.dtype == CP360_F32) return false;
+    cp360_wino_desc d1, d2, dg;
+    wino_descs(Cl, 6 * n_clips, face, &d1, &d2, &dg);
+    return cp360_wino_preferred(&d2) == 1;
+}
 
 }  // namespace
 
@@ -739,10 +757,45 @@ extern "C" int cp360_clstm_load(cp360_ctx* ctx, int dtype, const float* w1, cons
     return CP360_OK;
 }
 
+// 0: a cell update on n_clips cubes of face x face runs on the direct kernels; 1: in the Winograd domain (filters loaded); 2: it
+// would, once cp360_clstm_load_wino has been called - until then cp360_clstm_step / cp360_clstm_window take the direct kernels
+extern "C" int cp360_clstm_wino_state(cp360_ctx* ctx, int n_clips, int face) {
+    if (!ctx || !ctx->cl.loaded || n_clips <= 0 || face <= 0) return 0;
+    if (!wino_wanted(ctx->cl, n_clips, face)) return 0;
+    return ctx->cl.wino_loaded ? 1 : 2;
+}
+
+// Pack U = G g G^T of the three filters (f32 OIHW on the device, as cp360_clstm_load's) for the Winograd path: 16 / 9 of the
+// direct packing's bytes (1.28 GB at 1000 hidden channels), so it is made only when a launch shape asks for it.
+extern "C" int cp360_clstm_load_wino(cp360_ctx* ctx, const float* w1, const float* w2, const float* wg, void* stream) {
+    if (!ctx || !w1 || !w2 || !wg) return CP360_ERR_NULL;
+    CClstm& Cl = ctx->cl;
+    if (!Cl.loaded) return CP360_ERR_NULL;
+    if (Cl.dtype == CP360_F32) return CP360_ERR_BAD_DTYPE;
+    if (Cl.wino_loaded) return CP360_OK;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return CP360_ERR_HIP;
+    cp360_wino_desc d1, d2, dg;
+    wino_descs(Cl, 6, 8, &d1, &d2, &dg);
+    const cp360_wino_desc* ds[3] = {&d1, &d2, &dg};
+    const float* ws[3] = {w1, w2, wg};
+    void** us[3] = {&Cl.u1, &Cl.u2, &Cl.ug};
+    for (int k = 0; k < 3; ++k) {
+        const size_t nb = cp360_wino_packed_bytes(ds[k]);
+        if (!nb) return CP360_ERR_UNSUPPORTED;
+        if (!(*us[k] = ctx->own_clstm.take(nb))) return CP360_ERR_HIP;
+        const int rc = cp360_wino_pack_weights(ds[k], ws[k], *us[k], stream);
+        if (rc) return rc;
+    }
+    Cl.wino_loaded = true;
+    return CP360_OK;
+}
+
 namespace {
 struct ClstmWs {
     size_t act = 0, partial = 0;
-    size_t total() const { return 2 * act + partial; }
+    size_t wv = 0, wm = 0;                         // Winograd path: V (transformed input) and M (f32 position sums) instead of slabs
+    size_t total() const { return 2 * act + partial + wv + wm; }
 };
 
 int clstm_run(cp360_ctx* ctx, bool dry, void* xh, const float* c_prev, float* c_next, float* h_f32, int n_clips, int face,
@@ -771,6 +824,27 @@ int clstm_run(cp360_ctx* ctx, bool dry, void* xh, const float* c_prev, float* c_
         run.partial_cap = w.partial;
     }
     int rc, splits = 1;
+    if (Cl.wino_loaded && wino_wanted(Cl, n_clips, face)) {
+        // the same cell update in the Winograd domain (csrc/wino.hip): per convolution input transform -> 16 GEMMs -> output
+        // transform (+ bias + ReLU); the Gates convolution's output transform is the gate kernel
+        cp360_wino_desc d1, d2, dg;
+        wino_descs(Cl, n6, face, &d1, &d2, &dg);
+        w.wv = align_up(cp360_wino_v_bytes(&d2));
+        w.wm = align_up(cp360_wino_m_bytes(&d2));
+        if (dry) {
+            if (need) *need = w;
+            return CP360_OK;
+        }
+        if (ws_bytes < w.total()) return CP360_ERR_BAD_SHAPE;
+        unsigned char* v = ws + 2 * w.act;
+        float* m = (float*)(ws + 2 * w.act + w.wv);
+        if ((rc = cp360_wino_forward(&d1, xh, Cl.u1, Cl.c1.bias, a1, v, m, st))) return rc;
+        if ((rc = cp360_wino_forward(&d2, a1, Cl.u2, Cl.c2.bias, a2, v, m, st))) return rc;
+        if ((rc = cp360_wino_input(&dg, a2, v, st))) return rc;
+        if ((rc = cp360_wino_gemm(&dg, v, Cl.ug, m, st))) return rc;
+        return cp360_wino_output_gates(&dg, m, Cl.gbias, c_prev, c_next, xh, Cl.cin + Cl.ch, Cl.cin, h_f32, x_next, minmax, 0,
+                                       clip_stride, st);
+    }
     // clstm.py:55-64: cat(x, h) -> [CubePad(1) + conv3x3 + bias + relu] x 2 -> CubePad(1) + conv3x3 (Gates, bias in the gate kernel)
     if ((rc = run.conv(Cl.c1, xh, n6, face, face, nullptr, 0, a1, c4, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr))) return rc;
     if ((rc = run.conv(Cl.c2, a1, n6, face, face, nullptr, 0, a2, c4, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr))) return rc;

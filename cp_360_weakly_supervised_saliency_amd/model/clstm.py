@@ -71,8 +71,22 @@ class ConvLSTMCell(nn.Module):
             }
             for k, name in (('c1', 'clstm.Conv1'), ('c2', 'clstm.Conv2'), ('g', 'clstm.Gates')):
                 self._plan[k].tag = name
+                self._plan[k].clip_only = True      # csrc/ctx.hip packs only the layout the face size's kernel reads
+            if dt != torch.float32:
+                # the Winograd F(2x2, 3x3) form of the same three convolutions (csrc/wino.hip), packed on first use: taken when
+                # the launch has enough tiles (cp360_wino_preferred: 4 clips of 7x7 faces, one clip of 16x16 faces, ...)
+                self._plan['w1'] = ops.WinoConv(self.Conv1.weight, self.Conv1.bias, True, dt, dev)
+                self._plan['w2'] = ops.WinoConv(self.Conv2.weight, self.Conv2.bias, True, dt, dev)
+                self._plan['wg'] = ops.WinoConv(self.Gates.weight, None, False, dt, dev)
+                for k, name in (('w1', 'clstm.Conv1'), ('w2', 'clstm.Conv2'), ('wg', 'clstm.Gates')):
+                    self._plan[k].tag = name
             self._plan_stamp = stamp
         return self._plan
+
+    def uses_winograd(self, n6, w):
+        """True when a cell update on n6 faces of w x w runs in the Winograd domain (the library's rule, on Conv2's shape)."""
+        p = self.plans()
+        return 'w2' in p and p['w2'].preferred(n6, w)
 
     def step_nhwc(self, xh, c_prev, c_next, h_f32=None, bufs=None, x_next=None):
         """One cell update on the fused layout.
@@ -91,12 +105,17 @@ class ConvLSTMCell(nn.Module):
             return
         p = self.plans()
         n6, w, _, _ = xh.shape
+        # x_next = (cam, minmax, P, clip_stride, t_next): the gate kernel also writes the next step's normalised input
+        xn = None if x_next is None else (x_next[0], x_next[1], 0, x_next[2], x_next[3], x_next[4])
+        if self.uses_winograd(n6, w):
+            a1 = p['w1'](xh, out=None if bufs is None else bufs[0])
+            a2 = p['w2'](a1, out=None if bufs is None else bufs[1])
+            p['wg'].gates(a2, p['gbias'], c_prev, c_next, xh, self.input_size, h_f32, x_next=xn)
+            return
         a1 = p['c1'](xh, out=None if bufs is None else bufs[0])
         a2 = p['c2'](a1, out=None if bufs is None else bufs[1])
         sr = (4 * self.hidden_size) % 32 == 0              # gate slabs in packed-row order (64-byte stores)
         partial, splits = p['g'](a2, raw_f32=True, slab_rows=sr)
-        # x_next = (cam, minmax, P, clip_stride, t_next): the gate kernel also writes the next step's normalised input
-        xn = None if x_next is None else (x_next[0], x_next[1], 0, x_next[2], x_next[3], x_next[4])
         ops.lstm_gates(partial, splits, p['gbias'], c_prev, c_next, xh, self.input_size, h_f32,
                        n6 * w * w, self.hidden_size, slab_rows=sr, x_next=xn)
 

@@ -202,6 +202,15 @@ class ClstmStage(_Stage):
         torch.cuda.current_stream().synchronize()
         self.stamp = stamp
 
+    def _load_wino(self, B, w):
+        """The Winograd-domain filters, packed the first time a launch shape asks for them (cp360_clstm_wino_state == 2)."""
+        if lib().cp360_clstm_wino_state(self.ctx.h, int(B), int(w)) != 2:
+            return
+        c = self.cell
+        ts = [_f32(t) for t in (c.Conv1.weight, c.Conv2.weight, c.Gates.weight)]
+        _load_retry(lambda: lib().cp360_clstm_load_wino(self.ctx.h, *[ptr(t) for t in ts], stream()))
+        torch.cuda.current_stream().synchronize()
+
     def step(self, xh, c_prev, c_next, h_f32=None, x_next=None):
         """One cell update on the fused layout (see ConvLSTMCell.step_nhwc); x_next = (cam, minmax, P, clip_stride, t_next)."""
         n6, w = xh.shape[0], xh.shape[1]
@@ -215,6 +224,7 @@ class ClstmStage(_Stage):
             if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < n6 * w * w * c.hidden_size):
                 raise ValueError("%s must be a contiguous f32 [6B, w, w, H] tensor" % name)
         B = n6 // 6
+        self._load_wino(B, w)
         nbytes = lib().cp360_clstm_workspace_bytes(self.ctx.h, B, w)
         ws = self.ctx.workspace(('clstm', B, w), nbytes)
         xp, mm, stride = None, None, 0
@@ -234,6 +244,7 @@ class ClstmStage(_Stage):
         cam f32 (window b at + b * clip_stride elements; 0 = dense [B, T, P, C]); h_out f32 [6B, w, w, H] = the final hidden
         state; h_all (optional) f32 [T, 6B, w, w, H] = the hidden state after every step."""
         self._load(w)
+        self._load_wino(B, w)
         c = self.cell
         dt = precision_dtype(c.precision)
         require_gpu(cam, xh, cells[0], cells[1], h_out, minmax, scratch, h_all)

@@ -425,6 +425,14 @@ int cp360_resnet_forward(cp360_ctx* ctx, const void* faces_p3, int n_img, int cu
  * face size the cell will run at (7 at cube 224, 16 at cube 512): it selects the weight layout of the kernel for that size. */
 int cp360_clstm_load(cp360_ctx* ctx, int dtype, const float* w1, const float* b1, const float* w2, const float* b2,
                      const float* wg, const float* bg, int input_size, int hidden_size, int face, void* stream);
+/* The 16-bit cell in the Winograd domain ("K5w" above): when a launch shape has enough tiles (cp360_wino_preferred on Conv2's
+ * shape - e.g. 4 cubes of 7x7 faces, one cube of 16x16 faces) cp360_clstm_step / cp360_clstm_window run the three convolutions
+ * as F(2x2, 3x3).  Its filters (16 / 9 of the direct packing's bytes) are packed on request:
+ *   cp360_clstm_wino_state  0: (n_clips, face) runs on the direct kernels; 1: in the Winograd domain; 2: it would, but
+ *                           cp360_clstm_load_wino has not been called - the direct kernels run until it has
+ *   cp360_clstm_load_wino   the same f32 filters as cp360_clstm_load (call it after that; workspace sizes change with it). */
+int cp360_clstm_wino_state(cp360_ctx* ctx, int n_clips, int face);
+int cp360_clstm_load_wino(cp360_ctx* ctx, const float* w1, const float* w2, const float* wg, void* stream);
 size_t cp360_clstm_workspace_bytes(cp360_ctx* ctx, int n_clips, int face);
 /* One cell update for n_clips cubes in lock step on the fused layout: xh [6 n_clips, face, face, Cin + H] (loaded dtype):
  * channels [0, Cin) = the input frame, [Cin, Cin + H) = the previous hidden state - the NEW hidden state is written
