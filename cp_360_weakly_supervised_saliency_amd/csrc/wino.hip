@@ -89,6 +89,26 @@ __device__ __forceinline__ void fill(const unsigned char* ub, const unsigned cha
         : "memory", "scc");
 }
 
+// one of the five (WINO_DMA_PLACE != 0: they are spread between the MFMA columns)
+__device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off, unsigned dst, bool is_u) {
+    unsigned keep;
+    if (is_u)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WINO_UPOL "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WINO_VPOL "\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+}
+
+// placement of a sub-step's five refill DMAs (tools/wino_variants.sh A/B): 0 = all in front of the HEAD's MFMAs, 1 = one behind each
+// of the HEAD's first five MFMA columns, 2 = one behind each of the TAIL's first five columns
+#ifndef WINO_DMA_PLACE
+#define WINO_DMA_PLACE 0
+#endif
+#ifndef WINO_ABL
+#define WINO_ABL 0          // timing ablations (tools/wino_variants.sh): 1 = every U block aliases the first, 2 = every V block, 4 = no MFMA
+#endif
+
 // K loop + slab stores of one wave: channels [wch0, +64) x tile rows [wrow0, +192) = 4 x 12 MFMA blocks (192 accumulator
 // registers).  A sub-step is a HEAD (fragment reads, the refill DMAs, the first 6 columns; a column's registers are re-loaded
 // with column 6 + j as soon as its MFMAs are issued) and a TAIL (the other 6 columns, from registers); the two waves of a
@@ -113,11 +133,20 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lrow = lane & 15, lchunk = lane >> 4;
+    unsigned rdst = 0;                                            // LDS destination of the refill being spread (WINO_DMA_PLACE != 0)
+    auto issue_q = [&](int q) __attribute__((always_inline)) {   // DMA q of the refill: 0, 1 = U passes, 2, 3, 4 = V passes
+        if (q < 2) fill_one(ub, q == 0 ? o0 : o1, rdst + q * 0x2000, true);
+        else fill_one(vb, q == 2 ? o0 : q == 3 ? o1 : o2, rdst + q * 0x2000, false);
+    };
+    auto issue_begin = [&](int stage) __attribute__((always_inline)) {
+        rdst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE);
+    };
+    auto issue_end = [&]() __attribute__((always_inline)) {
+        if (!(WINO_ABL & 1)) ub += WG_BN * 64;
+        if (!(WINO_ABL & 2)) vb += vstep;
+    };
     auto issue = [&](int stage) __attribute__((always_inline)) {
         fill(ub, vb, o0, o1, o2, __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE));
-#ifndef WINO_ABL
-#define WINO_ABL 0          // timing ablations (tools/wino_variants.sh): 1 = every U block aliases the first, 2 = every V block, 4 = no MFMA
-#endif
         if (!(WINO_ABL & 1)) ub += WG_BN * 64;
         if (!(WINO_ABL & 2)) vb += vstep;
     };
@@ -145,28 +174,36 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
             a[i] = *reinterpret_cast<const u32x4*>(As + swz64(wch0 + i * 16 + lrow, lchunk));              \
         _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                     \
             b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + j * 16 + lrow, lchunk));             \
-        if (REFILL) issue(stage == 0 ? NS - 1 : stage - 1);                                                \
+        if (REFILL && WINO_DMA_PLACE == 0) issue(stage == 0 ? NS - 1 : stage - 1);                         \
+        if (REFILL && WINO_DMA_PLACE != 0) issue_begin(stage == 0 ? NS - 1 : stage - 1);                   \
         _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                                   \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j]);                 \
             b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + (JH + j) * 16 + lrow, lchunk));      \
+            if (REFILL && WINO_DMA_PLACE == 1 && j < 5) issue_q(j);                                        \
         }                                                                                                  \
+        if (REFILL && WINO_DMA_PLACE == 1) issue_end();                                                    \
         stage = stage == NS - 1 ? 0 : stage + 1;                                                           \
     }
-#define WINO_TAIL()                                                                                        \
+#define WINO_TAIL(REFILL)                                                                                  \
     {                                                                                                      \
-        _Pragma("unroll") for (int j = JH; j < MJ; ++j)                                                    \
+        /* a lagging wave's TAIL runs in front of its HEAD: the stage freed last is the one behind `stage` */ \
+        if (REFILL && WINO_DMA_PLACE == 2 && LAG) issue_begin(stage == 0 ? NS - 1 : stage - 1);            \
+        _Pragma("unroll") for (int j = JH; j < MJ; ++j) {                                                  \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j - JH]);            \
+            if (REFILL && WINO_DMA_PLACE == 2 && j - JH < 5) issue_q(j - JH);                              \
+        }                                                                                                  \
+        if (REFILL && WINO_DMA_PLACE == 2) issue_end();                                                    \
     }
 #define WINO_STEP(REFILL)                                                                                  \
     {                                                                                                      \
         if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
         __builtin_amdgcn_s_barrier();                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if (!LAG) WINO_HEAD(REFILL) else WINO_TAIL()                                                       \
+        if (!LAG) WINO_HEAD(REFILL) else WINO_TAIL(REFILL)                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         __builtin_amdgcn_s_barrier();                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        if (!LAG) WINO_TAIL() else WINO_HEAD(REFILL)                                                       \
+        if (!LAG) WINO_TAIL(REFILL) else WINO_HEAD(REFILL)                                                 \
     }
     int it = 0;
     for (; it + NS - 1 < nsub; ++it) {
@@ -177,7 +214,7 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         vm_wait_upto<(NS - 2) * D>(min(NS - 2, nsub - 1 - it) * D);
         WINO_STEP(false)
     }
-    if (LAG) WINO_TAIL()
+    if (LAG) WINO_TAIL(false)
 #undef WINO_STEP
 #undef WINO_HEAD
 #undef WINO_TAIL
@@ -185,6 +222,15 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
     // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores; the four lane
     // groups of a tile row write 64 contiguous bytes, the four blocks of a wave 256)
     float* mp = p.m + ((size_t)pos * p.m_pad + (size_t)mt_i * WG_BM + wrow0 + lrow) * p.ldm + nt_i * WG_BN + wch0 + lchunk * 4;
+    // (tile rows outermost: the four 64-byte pieces of a row's 256 bytes leave back to back and merge into full lines in L2)
+#ifndef WINO_STORE_IJ
+#pragma unroll
+    for (int j = 0; j < MJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out)
+                *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 >= p.c_out) continue;
@@ -192,6 +238,7 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         for (int j = 0; j < MJ; ++j)
             *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
     }
+#endif
 }
 
 template <typename T>
@@ -316,60 +363,52 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, 
 
 // ------------------------------------------------------------------ Y = A^T M A + bias, A^T = [[1,1,1,0],[0,1,-1,-1]]
 // s[a][j] = sum_i A^T[a][i] M[i][j] column by column, then Y[a][0] = s[a][0] + s[a][1] + s[a][2], Y[a][1] = s[a][1] - s[a][2] - s[a][3].
-template <int NC>      // NC f32 channels per thread (4 or 8): loads NC/4 float4 per position
-__device__ __forceinline__ void out_transform(const float* __restrict__ mp, size_t pstride, float (&y)[4][NC]) {
+// The 16 position values of a (tile, 4-channel group) are requested together (16 independent 16-byte loads in flight per call;
+// callers issue two or four calls before the first use: these kernels have few threads per CU and live on memory parallelism).
+// Address = (uniform plane base) + (32-bit per-thread byte offset): the "scalar base + vector offset" load form, one offset register
+// for all 16 loads instead of 16 64-bit pointers.
+__device__ __forceinline__ void load_positions(const float* __restrict__ m, size_t pstride, unsigned voff, f32x4 (&mm)[16]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int k = 0; k < NC; ++k) y[q][k] = 0.f;
+    for (int p = 0; p < 16; ++p)
+        mm[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(m + (size_t)p * pstride) + voff);
+}
+__device__ __forceinline__ void out_transform(const f32x4 (&mm)[16], f32x4 (&y)[4]) {
+    f32x4 s0[4], s1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float mm[4][NC];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int h = 0; h < NC / 4; ++h) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(mp + (size_t)(i * 4 + j) * pstride + h * 4);
-                mm[i][h * 4 + 0] = t[0]; mm[i][h * 4 + 1] = t[1]; mm[i][h * 4 + 2] = t[2]; mm[i][h * 4 + 3] = t[3];
-            }
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const float s0 = mm[0][k] + mm[1][k] + mm[2][k], s1 = mm[1][k] - mm[2][k] - mm[3][k];
-            if (j < 3) { y[0][k] += s0; y[2][k] += s1; }                        // column 0 of Y: + for j = 0, 1, 2
-            if (j == 1) { y[1][k] += s0; y[3][k] += s1; }                       // column 1 of Y: + j = 1, - j = 2, 3
-            if (j >= 2) { y[1][k] -= s0; y[3][k] -= s1; }
-        }
+        s0[j] = mm[j] + mm[4 + j] + mm[8 + j];
+        s1[j] = mm[4 + j] - mm[8 + j] - mm[12 + j];
     }
+    y[0] = s0[0] + s0[1] + s0[2];
+    y[1] = s0[1] - s0[2] - s0[3];
+    y[2] = s1[0] + s1[1] + s1[2];
+    y[3] = s1[1] - s1[2] - s1[3];
 }
 
+// One thread per (tile, 4-channel group): 16 independent 16-byte loads, 8-byte (16-bit types) stores; 384 k threads at 4 clips of 7x7
+// faces.  (8 channels per thread - 32 loads up front, 152 registers - measured 22 us against 17 for the same bytes.)
 template <typename T>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                        T* __restrict__ out, int tiles, int w, int th, int c_out, int ldm,
                                                        int m_pad, int ld_out, int out_coff, int relu) {
-    const int ng = c_out >> 3;
+    const int ng = c_out >> 2;
     const long long total = (long long)tiles * ng;
     const size_t pstride = (size_t)m_pad * ldm;
     const int tpf = th * th;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int tg = (int)(idx / ng), c = (int)(idx - (long long)tg * ng) * 8;
-        float y[4][8];
-        out_transform<8>(m + (size_t)tg * ldm + c, pstride, y);
-        float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + c), b1 = *reinterpret_cast<const f32x4*>(bias + c + 4);
-            b[0] = b0[0]; b[1] = b0[1]; b[2] = b0[2]; b[3] = b0[3]; b[4] = b1[0]; b[5] = b1[1]; b[6] = b1[2]; b[7] = b1[3];
-        }
+        const int tg = (int)(idx / ng), c = (int)(idx - (long long)tg * ng) * 4;
+        f32x4 mm[16], y[4];
+        load_positions(m, pstride, (unsigned)((tg * ldm + c) * 4), mm);          // < 2^32: checked at launch
+        const f32x4 bb = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        out_transform(mm, y);
         const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
             if (oy >= w || ox >= w) continue;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                y[q][k] += b[k];
-                if (relu) y[q][k] = fmaxf(y[q][k], 0.f);
-            }
-            *reinterpret_cast<u32x4*>(out + ((size_t)(img * w + oy) * w + ox) * ld_out + out_coff + c) = pack8(y[q], T());
+            float v[4] = {y[q][0] + bb[0], y[q][1] + bb[1], y[q][2] + bb[2], y[q][3] + bb[3]};
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            store4(out + ((size_t)(img * w + oy) * w + ox) * ld_out + out_coff + c, v);
         }
     }
 }
@@ -378,6 +417,10 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // with the optional window normalisation of the NEXT frame into the x half (as lstm_gates_kernel, conv_igemm.hip).
 __device__ __forceinline__ float wsigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
+// A block = 64 (tile, 4-channel group) items x 4 waves.  Wave k brings in gate k's 16 positions of every item (1 KiB contiguous
+// per position and wave: 16 independent loads in flight per lane - with one thread per item doing all four gates the launch
+// had 96 k threads of 64 dependent-ish loads each and ran at a third of the memory system's rate), transforms them and leaves the
+// item's four pixels in LDS; after the barrier wave q finishes pixel q of every item from the four gates.
 template <typename T>
 __global__ __launch_bounds__(256) void wino_gates_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                          const float* __restrict__ c_prev, float* __restrict__ c_next,
@@ -385,46 +428,47 @@ __global__ __launch_bounds__(256) void wino_gates_kernel(const float* __restrict
                                                          int tiles, int w, int th, int Hc, int ldm, int m_pad,
                                                          const float* __restrict__ x_next, const float* __restrict__ minmax,
                                                          int x_coff, size_t clip_stride) {
+    __shared__ f32x4 ex[4][4][64];                                 // [gate][pixel][item]: lanes of a wave touch consecutive 16-byte slots
     const int ng = Hc >> 2;
     const long long total = (long long)tiles * ng;
     const size_t pstride = (size_t)m_pad * ldm;
     const int tpf = th * th, P = 6 * w * w;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int tg = (int)(idx / ng), j = (int)(idx - (long long)tg * ng) * 4;
-        float g[4][4][4];                                          // [gate][pixel of the tile][channel]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + lane;
+    const bool live = idx < total;
+    const int tg = live ? (int)(idx / ng) : 0, j = live ? (int)(idx - (long long)tg * ng) * 4 : 0;
+    {
+        f32x4 mm[16], y[4];
+        load_positions(m, pstride, (unsigned)((tg * ldm + wv * Hc + j) * 4), mm);     // < 2^32: checked at launch
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + wv * Hc + j);
+        out_transform(mm, y);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            out_transform<4>(m + (size_t)tg * ldm + k * Hc + j, pstride, g[k]);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + k * Hc + j);
+        for (int q = 0; q < 4; ++q) ex[wv][q][lane] = y[q] + bb;
+    }
+    __syncthreads();
+    const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
+    const int oy = 2 * ty + (wv >> 1), ox = 2 * tx + (wv & 1);
+    if (!live || oy >= w || ox >= w) return;
+    const size_t mpx = (size_t)(img * w + oy) * w + ox;
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + mpx * Hc + j);
+    const f32x4 gi = ex[0][wv][lane], gf = ex[1][wv][lane], go = ex[2][wv][lane], gc = ex[3][wv][lane];
+    float cn[4], hn[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { g[k][q][0] += bb[0]; g[k][q][1] += bb[1]; g[k][q][2] += bb[2]; g[k][q][3] += bb[3]; }
-        }
-        const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
-            if (oy >= w || ox >= w) continue;
-            const size_t mpx = (size_t)(img * w + oy) * w + ox;
-            const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + mpx * Hc + j);
-            float cn[4], hn[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float ig = wsigmoid(g[0][q][e]), fg = wsigmoid(g[1][q][e]), og = wsigmoid(g[2][q][e]);
-                const float cg = tanhf(g[3][q][e]);
-                cn[e] = fg * cp[e] + ig * cg;
-                hn[e] = og * tanhf(cn[e]);
-            }
-            *reinterpret_cast<f32x4*>(c_next + mpx * Hc + j) = f32x4{cn[0], cn[1], cn[2], cn[3]};
-            store4(h_out + mpx * ld_h + h_coff + j, hn);
-            if (h_f32) *reinterpret_cast<f32x4*>(h_f32 + mpx * Hc + j) = f32x4{hn[0], hn[1], hn[2], hn[3]};
-            if (x_next) {
-                const int b = (int)(mpx / P), pix = (int)(mpx - (size_t)b * P);
-                const float mn = minmax[2 * b], den = minmax[2 * b + 1] - mn;
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x_next + (size_t)b * clip_stride + (size_t)pix * Hc + j);
-                const float xn[4] = {(xv[0] - mn) / den, (xv[1] - mn) / den, (xv[2] - mn) / den, (xv[3] - mn) / den};
-                store4(h_out + mpx * ld_h + x_coff + j, xn);
-            }
-        }
+    for (int e = 0; e < 4; ++e) {
+        const float ig = wsigmoid(gi[e]), fg = wsigmoid(gf[e]), og = wsigmoid(go[e]);
+        const float cg = tanhf(gc[e]);
+        cn[e] = fg * cp[e] + ig * cg;
+        hn[e] = og * tanhf(cn[e]);
+    }
+    *reinterpret_cast<f32x4*>(c_next + mpx * Hc + j) = f32x4{cn[0], cn[1], cn[2], cn[3]};
+    store4(h_out + mpx * ld_h + h_coff + j, hn);
+    if (h_f32) *reinterpret_cast<f32x4*>(h_f32 + mpx * Hc + j) = f32x4{hn[0], hn[1], hn[2], hn[3]};
+    if (x_next) {
+        const int b = (int)(mpx / P), pix = (int)(mpx - (size_t)b * P);
+        const float mn = minmax[2 * b], den = minmax[2 * b + 1] - mn;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x_next + (size_t)b * clip_stride + (size_t)pix * Hc + j);
+        const float xn[4] = {(xv[0] - mn) / den, (xv[1] - mn) / den, (xv[2] - mn) / den, (xv[3] - mn) / den};
+        store4(h_out + mpx * ld_h + x_coff + j, xn);
     }
 }
 
@@ -450,6 +494,7 @@ int wino_check(const cp360_wino_desc* d, WinoGeom* g) {
     g->nsub = (d->c_in + 31) / 32;
     g->nt = (d->c_out + WG_BN - 1) / WG_BN;
     g->ldm = d->c_out;
+    if ((long long)g->m_pad * g->ldm * 4 >= (1LL << 32)) return CP360_ERR_BAD_SHAPE;      // 32-bit byte offsets inside one position's plane of M
     return CP360_OK;
 }
 }  // namespace
@@ -540,9 +585,9 @@ extern "C" int cp360_wino_output(const cp360_wino_desc* d, const float* m, const
     if (rc) return rc;
     if (!m || !out) return CP360_ERR_NULL;
     const int ld_out = d->ld_out ? d->ld_out : d->c_out;
-    const long long total = (long long)g.tiles * (d->c_out / 8);
+    const long long total = (long long)g.tiles * (d->c_out / 4);
     long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == CP360_F16)
         hipLaunchKernelGGL((wino_out_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (f16_raw*)out, g.tiles, d->face, g.th,
@@ -567,8 +612,8 @@ extern "C" int cp360_wino_output_gates(const cp360_wino_desc* d, const float* m,
     if (x_next && (!minmax || x_coff % 4 != 0 || clip_stride % 4 != 0 || x_coff + Hc > ld_h || (x_coff < h_coff + Hc && h_coff < x_coff + Hc)))
         return CP360_ERR_BAD_SHAPE;
     const long long total = (long long)g.tiles * (Hc / 4);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    const long long blocks = (total + 63) / 64;                 // one 256-thread block per 64 items
+    if (blocks >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (d->dtype == CP360_F16)
         hipLaunchKernelGGL((wino_gates_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (f16_raw*)h_out, ld_h,

@@ -37,7 +37,7 @@ def main():
     # dominant kernel launches in the trace: the ConvLSTM K=36000 convs are the longest conv_igemm<.,2,2> launches
     tr = find(os.path.join(src, 'trace'), '*kernel_trace.csv')
     if tr:
-        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm' in r['Kernel_Name'] or 'conv_clip' in r['Kernel_Name']]
+        rows = [r for r in csv.DictReader(open(tr)) if 'conv_igemm' in r['Kernel_Name'] or 'conv_clip' in r['Kernel_Name'] or 'wino_gemm' in r['Kernel_Name']]
         by_grid = {}
         for r in rows:
             key = (r['Kernel_Name'][:60], r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])
@@ -54,8 +54,20 @@ def main():
         # the dominant kernel of bench.py = the K = 36000 ConvLSTM launches (Conv2 / Gates) of conv_clip_kernel;
         # Conv1 (K = 18000) and layer4's conv2 share the kernel and grid and take about half the time, so
         # split the launches of that kernel at 75 % of its longest launch
+        # round 5: with enough tiles the ConvLSTM runs in the Winograd domain and the dominant kernel is wino_gemm_kernel (K = 4000
+        # channels x 16 positions for Conv2 / Gates, K = 2000 for Conv1)
+        wino = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if 'wino_gemm' in r['Kernel_Name']]
+        if wino:
+            cut = 0.75 * max(wino)
+            big = [d for d in wino if d >= cut]
+            small = [d for d in wino if d < cut]
+            lines.append('')
+            lines.append('wino_gemm_kernel launches: %d of K = 4000 x 16 positions (ConvLSTM Conv2 / Gates in the Winograd domain, the dominant '
+                         'kernel of bench.py): avg %.1f us; %d shorter ones (Conv1, K = 2000): avg %.1f us'
+                         % (len(big), sum(big) / len(big), len(small), sum(small) / max(1, len(small))))
+            out['dominant_kernel'] = {'name': 'wino_gemm_kernel', 'launches': len(big), 'avg_us': sum(big) / len(big)}
         clip = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if 'conv_clip' in r['Kernel_Name']]
-        if clip:
+        if clip and not wino:
             cut = 0.75 * max(clip)
             big = [d for d in clip if d >= cut]
             small = [d for d in clip if d < cut]
@@ -65,13 +77,16 @@ def main():
                          % (len(big), sum(big) / len(big), len(small), sum(small) / max(1, len(small))))
             out['dominant_kernel'] = {'name': 'conv_clip_kernel', 'launches': len(big), 'avg_us': sum(big) / len(big)}
     pm = {}
+    is_wino = False
     for name in ('fetch', 'write'):
         f = find(os.path.join(src, name), '*counter_collection.csv')
         if not f:
             continue
         rows = list(csv.DictReader(open(f)))
         # the ConvLSTM convolutions: the clip-resident kernel when it ran, else the generic implicit GEMM
-        clip = [r for r in rows if 'conv_clip' in r['Kernel_Name']]
+        wino = [r for r in rows if 'wino_gemm' in r['Kernel_Name']]
+        is_wino = is_wino or bool(wino)
+        clip = wino if wino else [r for r in rows if 'conv_clip' in r['Kernel_Name']]
         rows = clip if clip else [r for r in rows if 'conv_igemm' in r['Kernel_Name']]
         by = {}
         for r in rows:
@@ -98,7 +113,12 @@ def main():
         lines.append('')
         # the algorithmic bytes depend on the launch shape (M = pixels of the batch, split-K factor): derived from the
         # write counter instead of quoted for one shape - one f32 slab of the 4000-channel output is M * 16 kB
-        lines.append('ConvLSTM conv launches (grid %s): FETCH_SIZE %.0f KiB (K=36000 launches; %.0f KiB over all three '
+        if is_wino:
+            lines.append('wino_gemm_kernel launches (grid %s): FETCH_SIZE %.0f KiB (K = 4000 launches; %.0f KiB over all three), WRITE_SIZE '
+                         '%.0f KiB per launch -> HBM traffic (2*FETCH + WRITE)*1024 = %.1f MB per K = 4000 launch (algorithmic: U 524 MB + V 49 MB '
+                         'read, M 98 MB written)' % (key, fe, sum(fv) / len(fv), wr, traffic / 1e6))
+        else:
+          lines.append('ConvLSTM conv launches (grid %s): FETCH_SIZE %.0f KiB (K=36000 launches; %.0f KiB over all three '
                      'convs), WRITE_SIZE %.0f KiB per launch -> HBM traffic (2*FETCH + WRITE)*1024 = %.1f MB per '
                      'K=36000 launch (algorithmic: 295 MB packed weights + the activations once + the f32 split-K slabs = the '
                      'write counter: %.0f MB = %.1f slabs of an M = 1176 launch (18.8 MB each) / of an M = 1536 launch (24.6 MB each: %.1f))'

@@ -45,13 +45,15 @@ for pos in (0, 5, 15):
 print('wino gemm max relative error vs torch (3 positions): %.2e' % worst)
 assert args.no_check or worst < 1e-3
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for rep in range(3):
+times = []
+for rep in range(7):
     a.record()
     for _ in range(args.iters):
         run()
     b.record()
     torch.cuda.synchronize()
-    ms = a.elapsed_time(b) / args.iters
-    fl = 2.0 * 16 * mpad * args.cout * args.cin
-    print('wino gemm  M=%d N=%d K=%d x16: %.1f us  %.0f TFLOP/s (Winograd-domain flops)  U stream %.2f TB/s'
-          % (mpad, args.cout, args.cin, ms * 1e3, fl / ms / 1e9, U.numel() * 2 / ms / 1e9), flush=True)
+    times.append(a.elapsed_time(b) / args.iters * 1e3)
+fl = 2.0 * 16 * mpad * args.cout * args.cin
+times.sort()
+print('wino gemm  M=%d N=%d K=%d x16: min %.1f median %.1f max %.1f us  (median: %.0f TFLOP/s Winograd-domain, U stream %.2f TB/s)'
+      % (mpad, args.cout, args.cin, times[0], times[3], times[-1], fl / times[3] / 1e6, U.numel() * 2 / times[3] / 1e6), flush=True)

@@ -8,10 +8,10 @@ for spec in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $C/wino.hip -o $D/wino.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so $(ls $C/*.o | grep -v wino.o) $D/wino.o
 done
-for rep in 1 2; do
+for rep in 1 2 3; do
 for spec in "$@"; do
   name=${spec%%:*}
   echo "== $name"
-  CP360_LIB=/tmp/wv_$name/libcp360.so python3 $R/tools/wino_probe.py $ARGS 2>&1 | grep "wino gemm" | tail -2
+  CP360_LIB=/tmp/wv_$name/libcp360.so python3 $R/tools/wino_probe.py $ARGS 2>&1 | grep "wino gemm" | tail -1
 done
 done
