@@ -164,15 +164,32 @@ def roofline_pass(eng, frames, precision, steps=2):
     tp = os.path.join(REPO, 'profiles', 'traffic_%s_b%d_w%d.json' % (precision, eng.B, eng.w))
     if not os.path.exists(tp) and (precision, eng.B, eng.w) == ('bf16', 4, 7):
         tp = os.path.join(REPO, 'profiles', 'traffic_bf16.json')
+    wino = precision != 'fp32' and eng.cell.uses_winograd(6 * eng.B, eng.w)
     if os.path.exists(tp):
         t = json.load(open(tp))
-        traffic, src = t.get('conv_igemm_clstm_bytes_per_launch'), 'profiles/' + t.get('source', '')
+        # (a summary collected for the OTHER kernel of this shape - the direct clip-resident one before round 5 - is not quoted)
+        if t.get('kernel', 'conv_clip_kernel').startswith('wino_gemm' if wino else 'conv_clip'):
+            traffic, src = t.get('conv_igemm_clstm_bytes_per_launch'), 'profiles/' + t.get('source', '')
     M = 6 * eng.B * eng.w * eng.w
-    return {'bound': 'mfma', 'kernel': 'conv_clip_kernel<%s> (ConvLSTM Conv2/Gates, M=%d N=%d K=%d)'
-            % ('face tile' if eng.w > 7 else 'clip tile', M, 4 * eng.cell.hidden_size, 36 * eng.cell.hidden_size),
-            'achieved': round(ach, 2), 'peak': PEAK[precision], 'unit': 'TFLOP/s', 'frac': round(ach / PEAK[precision], 4),
-            'traffic': traffic, 'traffic_source': src and (src + ' (rocprofv3 PMC passes, (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch; not re-measured in this run)'),
-            'avg_launch_ms': round(ms, 4), 'launches_timed': n, 'flops_per_launch': flops}
+    H4 = 4 * eng.cell.hidden_size
+    res = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK[precision], 'unit': 'TFLOP/s', 'frac': round(ach / PEAK[precision], 4),
+           'traffic': traffic, 'traffic_source': src and (src + ' (rocprofv3 PMC passes, (2*FETCH_SIZE+WRITE_SIZE)*1024 per launch; not re-measured in this run)'),
+           'avg_launch_ms': round(ms, 4), 'launches_timed': n, 'flops_per_launch': flops}
+    if wino:
+        # the launch computes the SAME convolution in the Winograd domain: `achieved` stays the convolution's algorithmic flops
+        # (2 M N 9 C) per launch time; what the matrix pipe really executes is 16 GEMMs over the padded tile count
+        th = (eng.w + 1) // 2
+        tiles = -(-6 * eng.B * th * th // 384) * 384
+        mf = 2.0 * 16 * tiles * H4 * H4
+        res['kernel'] = ('wino_gemm_kernel (ConvLSTM Conv2/Gates as Winograd F(2x2,3x3): 16 GEMMs of %d tiles x N=%d x K=%d; '
+                         'direct form M=%d N=%d K=%d)' % (tiles, H4, H4, M, H4, 9 * H4))
+        res['mfma_flops_per_launch'] = mf
+        res['mfma_frac'] = round(mf / (ms * 1e-3) / 1e12 / PEAK[precision], 4)
+        res['note'] = ('frac = algorithmic (direct-form) flops / launch time / peak; mfma_frac = the flops the matrix pipe executes '
+                       '(%.2f of the direct form) / the same time; the input / output transform kernels are separate launches' % (mf / flops))
+    else:
+        res['kernel'] = ('conv_clip_kernel<%s> (ConvLSTM Conv2/Gates, M=%d N=%d K=%d)' % ('face tile' if eng.w > 7 else 'clip tile', M, H4, 9 * H4))
+    return res
 
 
 STATIC_GFLOP = {224: 49.05 + 1.20, 256: 64.06 + 1.57, 512: 256.24 + 6.29}     # ResNet-50-cubic + CAM, per frame

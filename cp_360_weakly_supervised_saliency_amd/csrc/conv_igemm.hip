@@ -1534,6 +1534,21 @@ static int c_pad_of(const cp360_conv_desc* d) {
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static int c_pad2_of(const cp360_conv_desc* d) { return d->c_in2 > 0 ? round_up(d->c_in2, bk_of(d->dtype)) : 0; }
 
+// What conv_small_kernel (csrc/conv_small.hip) requires of a descriptor - ONE predicate for the planner (small_eligible) and
+// for a caller that forces the tile (tile_px == 6464, check_desc): shape limits -> UNSUPPORTED, alignment of its 16-byte
+// output / residual accesses in the 16-bit types -> ALIGN.
+static int small_shape_status(const cp360_conv_desc* d) {
+    if (d->clip_resident || d->c_out % 8 != 0) return CP360_ERR_UNSUPPORTED;
+    if (d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS) return CP360_ERR_UNSUPPORTED;
+    // 32-bit byte offsets inside the tensors and inside a tile's 64 weight rows
+    const long long es = elem_bytes(d->dtype);
+    if ((long long)d->n_img * d->h_in * d->w_in * d->pix_stride * es >= (1LL << 32)) return CP360_ERR_UNSUPPORTED;
+    if (d->c_in2 > 0 && (long long)d->n_img * d->h_in2 * d->w_in2 * d->pix_stride2 * es >= (1LL << 32)) return CP360_ERR_UNSUPPORTED;
+    if (64LL * ((long long)d->kh * d->kw * c_pad_of(d) + c_pad2_of(d)) * es >= (1LL << 32)) return CP360_ERR_UNSUPPORTED;
+    if (d->dtype != CP360_F32 && (d->ld_out % 8 != 0 || d->out_coff % 8 != 0 || d->ld_res % 8 != 0)) return CP360_ERR_ALIGN;
+    return CP360_OK;
+}
+
 static int check_desc(const cp360_conv_desc* d) {
     if (!d) return CP360_ERR_NULL;
     if (d->dtype != CP360_F32 && d->dtype != CP360_BF16 && d->dtype != CP360_F16) return CP360_ERR_BAD_DTYPE;
@@ -1544,10 +1559,10 @@ static int check_desc(const cp360_conv_desc* d) {
     if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 256 &&
         d->tile_px != 304 && d->tile_px != 6464)
         return CP360_ERR_BAD_SHAPE;
-    if (d->tile_px == 6464 && (d->clip_resident || d->c_out % 8 != 0 || d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS ||
-                               (long long)d->n_img * d->h_in * d->w_in * d->pix_stride * elem_bytes(d->dtype) >= (1LL << 32) ||
-                               (d->c_in2 > 0 && (long long)d->n_img * d->h_in2 * d->w_in2 * d->pix_stride2 * elem_bytes(d->dtype) >= (1LL << 32))))
-        return CP360_ERR_UNSUPPORTED;                                                                    // conv_small.hip
+    if (d->tile_px == 6464) {                                  // forced small tile: exactly what the planner requires of it
+        const int rc = small_shape_status(d);
+        if (rc) return rc;
+    }
     if (d->tile_px == 129 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;   // 16-bit types only (128-VGPR budget)
     if (d->slab_rows != 0 && d->slab_rows != 1) return CP360_ERR_BAD_SHAPE;
     if (d->slab_rows && d->c_out % 32 != 0) return CP360_ERR_ALIGN;
@@ -1639,18 +1654,8 @@ static bool small_eligible(const cp360_conv_desc* d) {
         const char* e = getenv("CP360_SMALL");               // A/B switch: 0 = never, 1 = f32 only (default), 2 = every dtype
         return e ? atoi(e) : 1;
     }();
-    if (!small || d->clip_resident || d->c_out % 8 != 0) return false;
-    if (d->kh * d->kw + (d->c_in2 > 0 ? 1 : 0) > CP360_SMALL_MAX_TAPS) return false;
-    // 32-bit byte offsets inside the tensors and inside a tile's 64 weight rows
-    const long long es = elem_bytes(d->dtype);
-    if ((long long)d->n_img * d->h_in * d->w_in * d->pix_stride * es >= (1LL << 32)) return false;
-    if (d->c_in2 > 0 && (long long)d->n_img * d->h_in2 * d->w_in2 * d->pix_stride2 * es >= (1LL << 32)) return false;
-    if (64LL * ((long long)d->kh * d->kw * c_pad_of(d) + c_pad2_of(d)) * es >= (1LL << 32)) return false;
-    if (d->dtype != CP360_F32) {
-        if (small < 2) return false;
-        if (d->ld_out % 8 != 0 || d->out_coff % 8 != 0 || d->ld_res % 8 != 0) return false;
-    }
-    return true;
+    if (!small || (d->dtype != CP360_F32 && small < 2)) return false;
+    return small_shape_status(d) == CP360_OK;
 }
 
 static ConvPlan plan_small(const cp360_conv_desc* d) {

@@ -46,22 +46,56 @@ def shard_clips(n_clips, rank, world):
     return list(range(lo, lo + base + (1 if rank < extra else 0)))
 
 
+# send / recv / result buffers of gather_maps, one set per (shape, dtype, device, n_clips, world): the all-gather sits inside
+# bench.py's timed loop, and a fresh zeros + empty + cat per step is ~5 small launches that a 6 ms step (one clip per GPU) sees
+_GATHER_BUFS = {}
+
+
+def _into_tensor_ok():
+    return hasattr(dist, 'all_gather_into_tensor') and dist.get_backend() != 'gloo'
+
+
 def gather_maps(local_maps, n_clips, rank, world):
     """local_maps: [len(shard_clips(...)), h, w] f32 on this rank's device - or [.., T, h, w] with the per-step
     maps of ``return_all_steps`` (any trailing shape).  Returns [n_clips, ...] on every rank, ordered by clip id
-    (one all_gather: 6 KB per rank at BASELINE config C4, 100 KB with all 16 per-step maps)."""
+    (one all_gather: 6 KB per rank at BASELINE config C4, 100 KB with all 16 per-step maps).
+
+    Nothing is allocated after the first call of a shape: an even split gathers straight into the (reused) result tensor,
+    a ragged one goes through a reused padded send / recv pair.  The result is overwritten by the next call with the same
+    shape - clone it to keep it."""
     if world == 1 and not dist.is_initialized():
         return local_maps
     base, extra = divmod(n_clips, world)
     cap = base + (1 if extra else 0)
     tail = tuple(local_maps.shape[1:])
-    send = torch.zeros((cap,) + tail, dtype=local_maps.dtype, device=local_maps.device)
-    send[: local_maps.shape[0]] = local_maps
-    recv = torch.empty((world, cap) + tail, dtype=local_maps.dtype, device=local_maps.device)
-    dist.all_gather_into_tensor(recv, send) if hasattr(dist, 'all_gather_into_tensor') and \
-        dist.get_backend() != 'gloo' else dist.all_gather(list(recv.unbind(0)), send)
-    parts = [recv[r, : base + (1 if r < extra else 0)] for r in range(world)]
-    return torch.cat(parts, dim=0)
+    key = (tail, local_maps.dtype, local_maps.device, n_clips, world)
+    bufs = _GATHER_BUFS.get(key)
+    if bufs is None:
+        mk = lambda *shape: torch.empty(shape + tail, dtype=local_maps.dtype, device=local_maps.device)
+        bufs = _GATHER_BUFS[key] = {'out': mk(n_clips)}
+        if extra:
+            bufs['send'] = torch.zeros((cap,) + tail, dtype=local_maps.dtype, device=local_maps.device)
+            bufs['recv'] = mk(world, cap)
+    out = bufs['out']
+    if not extra:                                    # even split: rank r's block IS rows [r * base, (r + 1) * base) of the result
+        send = local_maps if local_maps.is_contiguous() else local_maps.contiguous()
+        if _into_tensor_ok():
+            dist.all_gather_into_tensor(out, send)
+        else:
+            dist.all_gather(list(out.view((world, base) + tail).unbind(0)), send)
+        return out
+    send, recv = bufs['send'], bufs['recv']
+    send[: local_maps.shape[0]].copy_(local_maps)    # (rows past this rank's block stay zero from the allocation)
+    if _into_tensor_ok():
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        dist.all_gather(list(recv.unbind(0)), send)
+    lo = 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out[lo: lo + n].copy_(recv[r, :n])
+        lo += n
+    return out
 
 
 def max_over_ranks(value, device):

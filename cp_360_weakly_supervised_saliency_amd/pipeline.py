@@ -146,6 +146,10 @@ class SaliencyEngine:
                 side.synchronize()
                 self._fallback_to_bf16()
             flat = frames.reshape((B * T,) + tuple(frames.shape[2:]))
+            # the batch was allocated on the caller's stream and is READ on the side stream: tell the caching allocator, or the
+            # block could be handed to the caller's next allocation (the H2D of batch i+1) while the static stage still reads it
+            if frames.is_cuda:
+                frames.record_stream(side)
             buf = cams[i & 1]
             side.wait_stream(main)                         # the frames (and everything the caller queued) are ready
             if temporal_done[i & 1] is not None:

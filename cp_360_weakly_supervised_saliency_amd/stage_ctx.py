@@ -17,22 +17,51 @@ from ._lib import ConvBn, check, dtype_code, lib, precision_dtype, ptr, require_
 USE_CTX = os.environ.get('CP360_CTX', '1') != '0'
 
 
+# Every registration of a Parameter / buffer / submodule on ANY nn.Module (``m.weight = Parameter(..)``, ``model.fc = nn.Linear(..)``,
+# ``register_buffer``) bumps this counter through torch's global registration hooks: a cached tensor list made before such an
+# assignment is walked again.  (load_state_dict, .to() and .cuda() keep the objects and change data_ptr / _version instead.)
+_EPOCH = [0]
+
+
+def _bump(*_):
+    _EPOCH[0] += 1
+
+
+try:
+    from torch.nn.modules import module as _tm
+    _tm.register_module_parameter_registration_hook(_bump)
+    _tm.register_module_buffer_registration_hook(_bump)
+    _tm.register_module_module_registration_hook(_bump)
+    _HOOKED = True
+except (ImportError, AttributeError):                        # an older torch: walk the module on every call
+    _HOOKED = False
+
+
+def _sentinels(module):
+    """ids of the first parameter of the module and of each direct child: replaced wholesale by an ``_apply`` under
+    torch.__future__.set_overwrite_module_params_on_conversion (which bypasses the registration hooks)."""
+    return tuple(id(next(c.parameters(), None)) for c in [module] + list(module._modules.values()) if c is not None)
+
+
 def _stamp(module, extra=()):
     """(storage, version) of every parameter and buffer: changes when weights are loaded, moved, cast or updated in place.
     The tensor list itself is cached on the module (walking ``parameters()`` / ``buffers()`` of ResNet-50 is ~1 ms per call,
-    as much as one frame's static stage): it is rebuilt when a cached tensor has changed storage, and
-    ``module.__dict__.pop('_stage_tensors', None)`` forces it after replacing a Parameter OBJECT (not done anywhere on the
-    reference's path: load_state_dict, .to() and .cuda() keep the objects)."""
+    as much as one frame's static stage).  It is rebuilt when a cached tensor has changed storage, when anything has been
+    registered on any module since (``model.fc = nn.Linear(..)``, ``m.weight = Parameter(..)``: the global epoch above), or when
+    the first parameters of the module / its children are other objects than at caching time."""
     d = module.__dict__
     ts = d.get('_stage_tensors')
-    if ts is not None:
+    if ts is not None and _HOOKED and d.get('_stage_epoch') == _EPOCH[0] and d.get('_stage_sentinels') == _sentinels(module):
         st = tuple((t.data_ptr(), t._version) for t in ts)
         if st == d.get('_stage_last'):
-            return st + tuple(extra)
+            return st + (d.get('_stage_ids'),) + tuple(extra)
     # first call, or something changed: walk the module again (.to() / .cuda() replace the BUFFER objects)
     ts = d['_stage_tensors'] = list(module.parameters()) + list(module.buffers())
+    d['_stage_epoch'], d['_stage_sentinels'] = _EPOCH[0], _sentinels(module)
     st = d['_stage_last'] = tuple((t.data_ptr(), t._version) for t in ts)
-    return st + tuple(extra)
+    # (object identity is part of the key: a replaced Parameter that landed on the old one's storage address must not look unchanged)
+    d['_stage_ids'] = hash(tuple(id(t) for t in ts))
+    return st + (d['_stage_ids'],) + tuple(extra)
 
 
 class StageCtx:

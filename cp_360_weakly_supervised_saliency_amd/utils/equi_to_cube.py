@@ -115,8 +115,9 @@ class Equi2Cube:
         img = np.asarray(in_image)
         # The frame crosses PCIe in the dtype it arrives in (the reference's driver hands in the float64 ``np.array(img) /
         # 255.0``) and is rounded to float32 on the device - the same IEEE rounding numpy's cast does, without a
-        # single-threaded pass over 6 M elements on the host.  Read-only / byte-swapped / exotic inputs: numpy converts.
-        if img.flags.writeable and img.dtype.isnative and img.dtype in _TORCH_CASTABLE:
+        # single-threaded pass over 6 M elements on the host.  Read-only / byte-swapped / negatively strided (``img[..., ::-1]``, a
+        # flipped frame: torch.from_numpy refuses those) / exotic inputs: numpy converts.
+        if img.flags.writeable and img.dtype.isnative and img.dtype in _TORCH_CASTABLE and all(st >= 0 for st in img.strides):
             x = torch.from_numpy(img).to(self.device)[None].to(torch.float32)
         else:
             x = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None].to(self.device)

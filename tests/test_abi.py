@@ -91,6 +91,18 @@ def test_conv_packed_size_and_desc_checks():
     d.n_img, d.splits = 6, 4
     assert L.cp360_conv_partial_bytes(C.byref(d)) == 4 * 294 * 4000 * 4
     assert torch is not None
+    # a FORCED small tile (tile_px 6464) is held to what the planner requires of conv_small_kernel: the 16-bit kernel moves
+    # residuals / outputs in 16-byte pieces (ld_out, out_coff, ld_res % 8), its weight offsets are 32-bit
+    one = C.c_void_p(16)
+    d.splits, d.tile_px, d.c_out, d.ld_out = 1, 6464, 4000, 4004
+    assert L.cp360_conv_forward(C.byref(d), one, one, None, None, one, None, None) == -6          # ld_out % 8 (bf16): ALIGN
+    d.dtype = 0
+    assert L.cp360_conv_packed_bytes(C.byref(d)) != 0                                             # f32: 4-element alignment is enough
+    d.dtype, d.ld_out, d.out_coff = 1, 4008, 4
+    assert L.cp360_conv_forward(C.byref(d), one, one, None, None, one, None, None) == -6          # out_coff % 8
+    d.ld_out, d.out_coff, d.c_in, d.pix_stride = 4000, 0, 40000000, 40000000                      # 64 rows x K bytes >= 2^32
+    d.n_img, d.h_in, d.w_in, d.h_out, d.w_out, d.kh, d.kw, d.pad_mode, d.pad = 6, 1, 1, 1, 1, 1, 1, 0, 0
+    assert L.cp360_conv_forward(C.byref(d), one, one, None, None, one, None, None) == -8          # UNSUPPORTED, not a wrapped offset
 
 
 def test_ops_refuse_cpu_tensors():

@@ -45,8 +45,13 @@ def _worker(rank, world, port, n_clips, q, all_steps=False):
     local = torch.from_numpy(np.stack([fake(c) for c in mine])) if mine else torch.zeros(empty)
     d.barrier()
     allmaps = d.gather_maps(local, n_clips, r, w)
+    first, ptr1 = allmaps.numpy().copy(), allmaps.data_ptr()
+    # a second step with other maps: nothing new is allocated (the same send / recv / result buffers) and the result is right
+    again = d.gather_maps(local + 1.0, n_clips, r, w)
+    assert again.data_ptr() == ptr1 and len(d._GATHER_BUFS) == 1, "gather_maps allocated on its second call"
+    assert np.array_equal(again.numpy(), first + 1.0)
     t = d.max_over_ranks(1.0 + r, 'cpu')
-    q.put((rank, mine, allmaps.numpy(), t))
+    q.put((rank, mine, first, t))
     torch.distributed.destroy_process_group()
 
 

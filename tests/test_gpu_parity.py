@@ -228,7 +228,8 @@ def test_equi2cube_matches_oracle(H, W, cd):
 def test_to_cube_staging_keeps_the_reference_semantics():
     """``Equi2Cube.to_cube`` (equi_to_cube.py:112-129) through its pinned staging buffers: fresh arrays per call (a later
     call does not change what an earlier one returned), the input's floating dtype, and the same faces for a float64, a
-    float32, a read-only and a non-contiguous view of the same frame (the last two take the numpy conversion path)."""
+    float32, a read-only, a non-contiguous and a negatively strided view of the same frame (the last ones take the numpy conversion
+    path)."""
     H, W, cd = 256, 512, 64
     e = Equi2Cube(cd, (H, W))
     a = synth.frame_u8(5, H, W).astype(np.float64) / 255.0
@@ -249,6 +250,15 @@ def test_to_cube_staging_keeps_the_reference_semantics():
     for f in range(6):
         assert f32[f].dtype == np.float32 and np.max(np.abs(f32[f] - keep[f])) <= 1e-6
         assert np.array_equal(fro[f], keep[f]) and np.array_equal(fnc[f], keep[f])
+    # negative strides (BGR -> RGB by a[..., ::-1], a vertically flipped frame): torch.from_numpy refuses them, the
+    # reference's cv2.remap of per-channel slices takes any strides
+    rev = dict(e.to_cube(a[..., ::-1]))
+    want_rev = dict(e.to_cube(np.ascontiguousarray(a[..., ::-1])))
+    flip = dict(e.to_cube(a[::-1]))
+    want_flip = dict(e.to_cube(np.ascontiguousarray(a[::-1])))
+    for f in range(6):
+        assert np.array_equal(rev[f], want_rev[f]) and np.array_equal(rev[f], keep[f][..., ::-1])
+        assert np.array_equal(flip[f], want_flip[f])
 
 
 # ------------------------------------------------------------------ K6 cube -> equi

@@ -44,3 +44,36 @@ def test_im_norm_in_place_and_sigmoid():
     out = im_norm(img, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     assert out is img and np.array_equal(out, want)                  # in place, same float64 operations
     assert np.allclose(sigmoid(np.array([0.0, 1.0])), [0.5, 1 / (1 + np.exp(-1.0))])
+
+
+def test_stage_stamp_sees_replaced_parameter_objects():
+    """stage_ctx._stamp (the key that decides when a stage context re-packs its weights) caches the module's tensor list; it
+    must still change when a Parameter / submodule OBJECT is replaced after the first forward (``model.fc = nn.Linear(..)``,
+    ``m.weight = Parameter(..)``), when weights are updated in place, and when ``_apply`` overwrites the parameters
+    (torch.__future__.set_overwrite_module_params_on_conversion) - and stay equal otherwise."""
+    import torch
+    import torch.nn as nn
+    from cp_360_weakly_supervised_saliency_amd import stage_ctx as sc
+    net = nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4), nn.Linear(4, 2))
+    a = sc._stamp(net)
+    assert sc._stamp(net) == a and sc._stamp(net, ('x',)) != a
+    net[2] = nn.Linear(4, 2)
+    b = sc._stamp(net)
+    assert b != a
+    net[0].weight = nn.Parameter(torch.zeros(4, 3, 1, 1))
+    c = sc._stamp(net)
+    assert c != b
+    with torch.no_grad():
+        net[0].weight.add_(1)
+    d = sc._stamp(net)
+    assert d != c
+    net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    e = sc._stamp(net)
+    assert e != d
+    torch.__future__.set_overwrite_module_params_on_conversion(True)
+    try:
+        net.double()
+    finally:
+        torch.__future__.set_overwrite_module_params_on_conversion(False)
+    f = sc._stamp(net)
+    assert f != e and sc._stamp(net) == f

@@ -153,6 +153,7 @@ def main():
     os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
     if len(sys.argv) > 3 and 'conv_igemm_clstm_bytes_per_launch' in out:      # the file bench.py reads `traffic` from
         json.dump({'conv_igemm_clstm_bytes_per_launch': out['conv_igemm_clstm_bytes_per_launch'],
+                   'kernel': out.get('dominant_kernel', {}).get('name', 'conv_clip_kernel'),
                    'source': os.path.basename(dst) + '.json'}, open(sys.argv[3], 'w'), indent=1)
     json.dump(out, open(dst + '.json', 'w'), indent=1)
     open(dst + '.md', 'w').write('\n'.join(lines) + '\n')
