@@ -36,9 +36,9 @@ template <int N> __device__ __forceinline__ void vm_wait_upto(int n) {
     else vm_wait_upto<N - 1>(n);
 }
 
-// One sub-step's fill, this wave's share: 2 + 3 LDS-DMA instructions of 1 KiB (16 rows x 64 B).  Both operand blocks are
-// contiguous (16 KiB of U, 24 KiB of V): "scalar base + 32-bit lane offset" addressing, M0 = the wave's LDS destination.
-// cache policy of the U (weight) / V stream loads: 0 default, 1 nt, 2 sc1, 3 sc0 sc1 (tools/wino_variants.sh A/B)
+// One LDS-DMA instruction = 1 KiB (16 tile rows x 64 B): "scalar base + 32-bit lane offset" addressing, M0 = the LDS destination.
+// Both operand blocks of a sub-step are contiguous (16 KiB of U, 24 KiB of V), so a sub-step's fill is 40 such instructions.
+// Cache policy of the U (weight) / V stream loads: 0 default, 1 nt, 2 sc1, 3 sc0 sc1 (tools/wino_variants.sh A/B: no difference)
 #ifndef WINO_UPOL_ID
 #define WINO_UPOL_ID 0
 #endif
@@ -63,33 +63,6 @@ template <int N> __device__ __forceinline__ void vm_wait_upto(int n) {
 #else
 #define WINO_VPOL ""
 #endif
-__device__ __forceinline__ void fill(const unsigned char* ub, const unsigned char* vb, unsigned o0, unsigned o1, unsigned o2,
-                                     unsigned dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %6\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %4" WINO_UPOL "\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %4" WINO_UPOL "\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5" WINO_VPOL "\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %5" WINO_VPOL "\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %5" WINO_VPOL "\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(o0), "v"(o1), "v"(o2), "s"(ub), "s"(vb), "s"(dst)
-        : "memory", "scc");
-}
-
-// one of the five (WINO_DMA_PLACE != 0: they are spread between the MFMA columns)
 __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off, unsigned dst, bool is_u) {
     unsigned keep;
     if (is_u)
@@ -100,30 +73,68 @@ __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off
                      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
 }
 
-// placement of a sub-step's five refill DMAs (tools/wino_variants.sh A/B): 0 = all in front of the HEAD's MFMAs, 1 = one behind each
-// of the HEAD's first five MFMA columns, 2 = one behind each of the TAIL's first five columns
+// ---- structure knobs (defaults = what tools/wino_stamps_ab.sh measured fastest; the others stay buildable for A/B)
+// WINO_LEAD_DMA 1: the four LEADING waves issue the whole fill (10 instructions each: their own 16-row slot and the slot of their
+//   SIMD partner), the lagging waves none.  The two waves of a SIMD meet at one barrier per sub-step; the one that wins the
+//   matrix-pipe arbitration (the older, leading wave) arrives ~600 cycles early and waits, the other sets the period - so the
+//   fill's issue time (~60-100 cycles per instruction) moves to the wave that has the slack.
+// WINO_DMA_PLACE 0: the refill in front of the HEAD's MFMAs, 2: spread behind the TAIL's MFMA columns, 3: behind the TAIL's last MFMA.
+// WINO_NO_B2 1: no second barrier per sub-step (it only paced the two wave groups; no LDS hazard depends on it).
+#ifndef WINO_LEAD_DMA
+#define WINO_LEAD_DMA 0
+#endif
 #ifndef WINO_DMA_PLACE
-#define WINO_DMA_PLACE 0
+#define WINO_DMA_PLACE 2
+#endif
+// WINO_HEAD_PRIO p > 0: a LAGGING wave raises its priority to p for the MFMAs of its HEAD (A/B)
+#ifndef WINO_HEAD_PRIO
+#define WINO_HEAD_PRIO 1
+#endif
+#ifndef WINO_NO_B2
+#define WINO_NO_B2 1
 #endif
 #ifndef WINO_ABL
 #define WINO_ABL 0          // timing ablations (tools/wino_variants.sh): 1 = every U block aliases the first, 2 = every V block, 4 = no MFMA
 #endif
+#if WINO_NO_B2
+#define WINO_B2()
+#else
+#define WINO_B2() __builtin_amdgcn_s_barrier();
+#endif
+
+// Diagnostic build only (-DWINO_STAMPS, tools/wino_stamps.sh): s_memtime stamps of waves 0 and 4 around the phases of sub-steps
+// WINO_STAMP_S0 .. +7 go to a buffer of their own; the product build executes no stamp.
+#ifdef WINO_STAMPS
+#ifndef WINO_STAMP_S0
+#define WINO_STAMP_S0 40
+#endif
+__device__ unsigned long long g_wino_stamps[256 * 2 * 8 * 6];
+#define WINO_STAMP(k)                                                                                      \
+    if ((wave & 3) == 0 && lane == 0 && it >= WINO_STAMP_S0 && it < WINO_STAMP_S0 + 8 && blockIdx.x < 256)    \
+        g_wino_stamps[((blockIdx.x * 2 + (wave >> 2)) * 8 + (it - WINO_STAMP_S0)) * 6 + (k)] = __builtin_amdgcn_s_memtime();
+#define WINO_STAMP_END() __builtin_amdgcn_sched_barrier(0); WINO_STAMP(5)
+#else
+#define WINO_STAMP(k)
+#define WINO_STAMP_END()
+#endif
 
 // K loop + slab stores of one wave: channels [wch0, +64) x tile rows [wrow0, +192) = 4 x 12 MFMA blocks (192 accumulator
-// registers).  A sub-step is a HEAD (fragment reads, the refill DMAs, the first 6 columns; a column's registers are re-loaded
+// registers).  A sub-step is a HEAD (fragment reads of its LDS stage, the first 6 columns; a column's registers are re-loaded
 // with column 6 + j as soon as its MFMAs are issued) and a TAIL (the other 6 columns, from registers); the two waves of a
-// SIMD (w and w + 4) run half a sub-step apart, as in conv_igemm_ring_kernel<T, 304>.
+// SIMD (w and w + 4) run half a sub-step apart (waves 4-7 LAG: their TAIL of sub-step s-1 comes before their HEAD of s).
 template <typename T, bool LAG>
 __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, const int pos, const int nt_i, const int mt_i,
                                           const int wave, const int lane, const int wch0, const int wrow0) {
-    constexpr int NS = WG_NS, D = 5, MJ = 12, JH = 6;
+    constexpr int NS = WG_NS, MJ = 12, JH = 6;
+    constexpr bool LOADER = !WINO_LEAD_DMA || !LAG;              // this wave issues DMAs
+    constexpr int NU = WINO_LEAD_DMA ? 10 : 5;                   // ... this many per sub-step
     const int nsub = p.nsub;
     const unsigned char* ub = p.u + ((size_t)(pos * p.nt + nt_i) * nsub) * (WG_BN * 64);
     const size_t vstep = (size_t)p.m_pad * 64;
     const unsigned char* vb = p.v + (size_t)pos * nsub * vstep + (size_t)mt_i * (WG_BM * 64);
-    // DMA role: lane l lands in row 16 * wave + (l >> 2) (+ 128 per pass), physical chunk l & 3, and fetches the logical chunk
+    // DMA role: lane l lands in row 16 * slot + (l >> 2) (+ 128 per pass), physical chunk l & 3, and fetches the logical chunk of
+    // that row (source-side swizzle); slot = the wave, and for a leading wave that loads for its partner also wave + 4 (+ 4 KiB)
     const unsigned o0 = (unsigned)((16 * wave + (lane >> 2)) * 64 + ((((lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3))) << 4));
-    const unsigned o1 = o0 + 0x2000, o2 = o0 + 0x4000;
     const unsigned lds_wave = (unsigned)(size_t)lds + (unsigned)wave * 1024;
 
     f32x4 acc[4][MJ];
@@ -133,26 +144,31 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lrow = lane & 15, lchunk = lane >> 4;
-    unsigned rdst = 0;                                            // LDS destination of the refill being spread (WINO_DMA_PLACE != 0)
-    auto issue_q = [&](int q) __attribute__((always_inline)) {   // DMA q of the refill: 0, 1 = U passes, 2, 3, 4 = V passes
-        if (q < 2) fill_one(ub, q == 0 ? o0 : o1, rdst + q * 0x2000, true);
-        else fill_one(vb, q == 2 ? o0 : q == 3 ? o1 : o2, rdst + q * 0x2000, false);
+    unsigned rdst = 0;                                            // LDS destination (this wave's slot) of the refill in progress
+    // unit u of a sub-step's fill: pass q = u % 5 (0, 1: the U block's two 128-row passes; 2, 3, 4: the V block's three), slot half
+    // u / 5 (the partner's rows: + 64 rows = + 4 KiB on both sides)
+    auto dma = [&](int u) __attribute__((always_inline)) {
+        const int q = u % 5, half = u / 5;
+        const unsigned src = o0 + (unsigned)((q < 2 ? q : q - 2) * 0x2000 + half * 0x1000);
+        fill_one(q < 2 ? ub : vb, src, rdst + (unsigned)(q * 0x2000 + half * 0x1000), q < 2);
     };
-    auto issue_begin = [&](int stage) __attribute__((always_inline)) {
+    auto refill_begin = [&](int stage) __attribute__((always_inline)) {
         rdst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE);
     };
-    auto issue_end = [&]() __attribute__((always_inline)) {
+    auto refill_end = [&]() __attribute__((always_inline)) {
         if (!(WINO_ABL & 1)) ub += WG_BN * 64;
         if (!(WINO_ABL & 2)) vb += vstep;
     };
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-        fill(ub, vb, o0, o1, o2, __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE));
-        if (!(WINO_ABL & 1)) ub += WG_BN * 64;
-        if (!(WINO_ABL & 2)) vb += vstep;
-    };
+    if (LOADER) {
 #pragma unroll
-    for (int k = 0; k < NS - 1; ++k)
-        if (k < nsub) issue(k);
+        for (int k = 0; k < NS - 1; ++k)
+            if (k < nsub) {
+                refill_begin(k);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) dma(u);
+                refill_end();
+            }
+    }
     int stage = 0;
     u32x4 a[4], b[JH];
     if (LAG) {
@@ -166,6 +182,8 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
 #else
 #define WINO_MMA(c, x, y) mma_chunk<T>(c, x, y)
 #endif
+    // REFILL: the stage read in the PREVIOUS sub-step (every wave finished with it before this sub-step's barrier) takes sub-step
+    // it + NS - 1.  A lagging wave's TAIL runs in front of its HEAD: the freed stage is the one behind `stage` there too.
 #define WINO_HEAD(REFILL)                                                                                  \
     {                                                                                                      \
         const unsigned char* As = lds + stage * WG_STAGE;                                                  \
@@ -174,44 +192,56 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
             a[i] = *reinterpret_cast<const u32x4*>(As + swz64(wch0 + i * 16 + lrow, lchunk));              \
         _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                     \
             b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + j * 16 + lrow, lchunk));             \
-        if (REFILL && WINO_DMA_PLACE == 0) issue(stage == 0 ? NS - 1 : stage - 1);                         \
-        if (REFILL && WINO_DMA_PLACE != 0) issue_begin(stage == 0 ? NS - 1 : stage - 1);                   \
+        if (LOADER && REFILL && (WINO_DMA_PLACE == 0 || !LAG)) refill_begin(stage == 0 ? NS - 1 : stage - 1); \
+        if (LOADER && REFILL && WINO_DMA_PLACE == 0) {                                                     \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u) dma(u);                                         \
+            refill_end();                                                                                  \
+        }                                                                                                  \
+        if (WINO_HEAD_PRIO > 0 && LAG) __builtin_amdgcn_s_setprio(WINO_HEAD_PRIO);                         \
         _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                                   \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j]);                 \
             b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + (JH + j) * 16 + lrow, lchunk));      \
-            if (REFILL && WINO_DMA_PLACE == 1 && j < 5) issue_q(j);                                        \
         }                                                                                                  \
-        if (REFILL && WINO_DMA_PLACE == 1) issue_end();                                                    \
+        if (WINO_HEAD_PRIO > 0 && LAG) __builtin_amdgcn_s_setprio(0);                                      \
         stage = stage == NS - 1 ? 0 : stage + 1;                                                           \
     }
 #define WINO_TAIL(REFILL)                                                                                  \
     {                                                                                                      \
-        /* a lagging wave's TAIL runs in front of its HEAD: the stage freed last is the one behind `stage` */ \
-        if (REFILL && WINO_DMA_PLACE == 2 && LAG) issue_begin(stage == 0 ? NS - 1 : stage - 1);            \
+        if (LOADER && REFILL && WINO_DMA_PLACE != 0 && LAG) refill_begin(stage == 0 ? NS - 1 : stage - 1); \
         _Pragma("unroll") for (int j = JH; j < MJ; ++j) {                                                  \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j - JH]);            \
-            if (REFILL && WINO_DMA_PLACE == 2 && j - JH < 5) issue_q(j - JH);                              \
+            if (LOADER && REFILL && WINO_DMA_PLACE == 2)                                                   \
+                _Pragma("unroll") for (int u = (j - JH) * (NU / 5); u < (j - JH + 1) * (NU / 5) && u < NU; ++u) dma(u); \
         }                                                                                                  \
-        if (REFILL && WINO_DMA_PLACE == 2) issue_end();                                                    \
+        if (LOADER && REFILL && WINO_DMA_PLACE == 3)                                                       \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u) dma(u);                                         \
+        if (LOADER && REFILL && WINO_DMA_PLACE != 0) refill_end();                                         \
     }
 #define WINO_STEP(REFILL)                                                                                  \
     {                                                                                                      \
         if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        WINO_STAMP(1)                                                                                      \
         __builtin_amdgcn_s_barrier();                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
+        WINO_STAMP(2)                                                                                      \
         if (!LAG) WINO_HEAD(REFILL) else WINO_TAIL(REFILL)                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        __builtin_amdgcn_s_barrier();                                                                      \
+        WINO_STAMP(3)                                                                                      \
+        WINO_B2()                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
+        WINO_STAMP(4)                                                                                      \
         if (!LAG) WINO_TAIL(REFILL) else WINO_HEAD(REFILL)                                                 \
+        WINO_STAMP_END()                                                                                   \
     }
+    // vmcnt (DMAs complete in issue order): before sub-step `it` its stage must have landed; younger are the NS - 2 stages behind it
     int it = 0;
     for (; it + NS - 1 < nsub; ++it) {
-        vm_wait<(NS - 2) * D>();
+        WINO_STAMP(0)
+        if (LOADER) vm_wait<(NS - 2) * NU>();
         WINO_STEP(true)
     }
     for (; it < nsub; ++it) {
-        vm_wait_upto<(NS - 2) * D>(min(NS - 2, nsub - 1 - it) * D);
+        if (LOADER) vm_wait_upto<(NS - 2) * NU>(min(NS - 2, nsub - 1 - it) * NU);
         WINO_STEP(false)
     }
     if (LAG) WINO_TAIL(false)
@@ -219,26 +249,15 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
 #undef WINO_HEAD
 #undef WINO_TAIL
 
-    // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores; the four lane
-    // groups of a tile row write 64 contiguous bytes, the four blocks of a wave 256)
+    // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores).  Tile rows outermost:
+    // the four 64-byte pieces of a row's 256 bytes leave back to back and merge into full lines in L2
     float* mp = p.m + ((size_t)pos * p.m_pad + (size_t)mt_i * WG_BM + wrow0 + lrow) * p.ldm + nt_i * WG_BN + wch0 + lchunk * 4;
-    // (tile rows outermost: the four 64-byte pieces of a row's 256 bytes leave back to back and merge into full lines in L2)
-#ifndef WINO_STORE_IJ
 #pragma unroll
     for (int j = 0; j < MJ; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out)
                 *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
-#else
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 >= p.c_out) continue;
-#pragma unroll
-        for (int j = 0; j < MJ; ++j)
-            *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
-    }
-#endif
 }
 
 template <typename T>
@@ -633,6 +652,12 @@ extern "C" int cp360_wino_forward(const cp360_wino_desc* d, const void* in, cons
     if ((rc = cp360_wino_gemm(d, v, packed, m, stream))) return rc;
     return cp360_wino_output(d, m, bias, out, stream);
 }
+
+#ifdef WINO_STAMPS
+extern "C" int cp360_wino_stamps_read(unsigned long long* host) {      // diagnostic build only
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamps), sizeof(g_wino_stamps)) == hipSuccess ? 0 : CP360_ERR_HIP;
+}
+#endif
 
 // the bare GEMM on caller-made operands (tools/wino_probe.py)
 extern "C" int cp360_wino_gemm_raw(int dtype, const void* u, const void* v, float* m, int nsub, int nt, int mt, int ldm,
