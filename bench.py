@@ -192,6 +192,15 @@ def roofline_pass(eng, frames, precision, steps=2):
     return res
 
 
+def pmc_clock(precision, B, w):
+    tp = os.path.join(REPO, 'profiles', 'pmc_clock_%s_b%d_w%s.json' % (precision, B, w))
+    if not os.path.exists(tp):
+        return None
+    t = json.load(open(tp))
+    return {'kernel': t.get('kernel'), 'clock_ghz': t.get('clock_ghz'), 'mfma_pipe_busy': t.get('mfma_pipe_busy'),
+            'source': 'profiles/' + t.get('source', '')}
+
+
 STATIC_GFLOP = {224: 49.05 + 1.20, 256: 64.06 + 1.57, 512: 256.24 + 6.29}     # ResNet-50-cubic + CAM, per frame
 
 
@@ -243,7 +252,7 @@ def static_roofline(ms_per_step, B, T, cd, precision):
 
 def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, graph=False, static_only=False,
                  frame_chunk=None, source_hw=None, want_roofline=False, static_precision=None, all_steps=False,
-                 f32_input=False, stub=False, want_split=False):
+                 f32_input=False, stub=False, want_split=False, want_plan=False, clock_after=False):
     if stub:
         eng = StubEngine(cd, B, T)
     else:
@@ -290,6 +299,10 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
     assert (static_only or out.shape[0] == n_clips) and bool(torch.isfinite(out).all())
     res = {'value': round(world * B * T * steps / elapsed, 3), 'ms_per_step': round(1000.0 * elapsed / steps, 3),
            'roofline': None}
+    if clock_after and not stub:
+        # the register-only MFMA clock probe, launched right behind the timed region's last step (the chip still warm)
+        res['held_clock_ghz_after'] = _safe(lambda: ops.held_clock_ghz(dev))
+        res['timed_region_s'] = round(elapsed, 3)
     # diagnosis of the N > 1 runs (never part of `value`): every rank's own ms per step and the all-gather alone
     res['ms_per_step_per_rank'] = [round(1000.0 * v / steps, 3) for v in cpdist.all_ranks(mine, dev)]
     if not static_only:
@@ -320,6 +333,17 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
             res['roofline'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     if static_only and not stub:
         res['roofline'] = static_roofline(res['ms_per_step'], B, T, cd, eng.static_precision)
+    if want_plan and not stub:
+        # which path the static stage takes at this cube size (cp360_resnet_plan_describe): fused kernels exist for cube 224 / 512
+        # in the 16-bit types, anything else runs convolution by convolution
+        try:
+            text = eng.resnet.__dict__['_stage'].describe(6 * B * T, cd)
+            lines = [ln for ln in text.splitlines() if ln and not ln.startswith('  ')]
+            res['static_plan'] = {'generic_layers': sum('GENERIC' in ln for ln in lines), 'fused_layers': sum('GENERIC' not in ln for ln in lines),
+                                  'lines': lines[:12]}
+            res['convlstm_winograd'] = bool(precision != 'fp32' and eng.cell.uses_winograd(6 * B, eng.w))
+        except Exception as e:                      # noqa: BLE001
+            res['static_plan'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     res['w'] = eng.w
     res['static_dtype'] = DTYPE[eng.static_precision]
     res['fp16_fallback'] = bool(eng.fp16_fallback)      # fp16 static stage overflowed on the first batch -> bf16 (pipeline.py)
@@ -396,11 +420,21 @@ def level1_bench(dev, precision='fp32', reps=5):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
     ts, tw = rate(static_frame), rate(temporal_window)
+    # where the temporal window's time is (tools/level1_breakdown.py --temporal): the reference's host loop ~1 ms, five f32 cell
+    # updates of ONE cube ~1.7 ms each = 0.79 of the f32 MFMA peak (f32 matrix rate = 1/16 of the 16-bit one) - device work, not
+    # shim overhead.  The same loop with the cell in bf16 (set_precision: the one-cube launches stay on the direct kernels):
+    cell.set_precision('bf16')
+    tw16 = rate(temporal_window)
+    cell.set_precision(precision)
     del model, cell
     torch.cuda.empty_cache()
     return {'name': 'Level-1 drop-in path (reference driver loops on the shims, numpy in / numpy out, %s)' % precision,
             'static_frames_per_s': round(1.0 / ts, 2), 'static_ms_per_frame': round(1000 * ts, 2),
             'temporal_maps_per_s': round(1.0 / tw, 2), 'temporal_ms_per_window': round(1000 * tw, 2),
+            'temporal_ms_per_window_bf16_cell': round(1000 * tw16, 2),
+            'temporal_breakdown': 'fp32: ~1 ms host loop of the reference (numpy min / max / normalise, 7 pageable H2D copies) + 5 cell updates of '
+                                  '~1.7 ms each on the device (211.7 GFLOP at 0.79 of the 157 TFLOP/s f32 MFMA peak) + 0.05 ms output; '
+                                  'tools/level1_breakdown.py --temporal',
             'window': 'seq_len 5 (config.yaml:34): 5 ConvLSTMCell calls + to_equi_nn + max',
             'what': 'to_cube dict -> im_norm -> CAM() per 1024x2048 frame; 5 x model(frame, [hidden, cell]) + '
                     'to_equi_nn + torch.max per window; PCIe copies and NCHW<->NHWC conversions of every call included'}
@@ -633,6 +667,10 @@ def main():
             # clock this chip holds under a dense bf16 MFMA load (boxes differ: MI355X_MICROARCH.md, DVFS give-back)
             'stage_ms': head.get('stage_ms'),
             'held_clock_ghz': None if args.stub_engine else _safe(lambda: ops.held_clock_ghz(dev)),
+            # ... that probe is a register-only MFMA loop: it ranks boxes, it is NOT the clock the dominant kernel holds (LDS, DMA
+            # and HBM traffic beside the matrix pipe draw power too).  The counter-derived clock of that kernel, from the tracked
+            # PMC summary of the same launch shape (SQ_BUSY_CYCLES / 32 / launch time; not re-measured in this run):
+            'dominant_kernel_clock': pmc_clock(args.precision, B, head.get('w')),
         }
         if args.stub_engine:
             line['stub_engine'] = True
@@ -656,9 +694,14 @@ def main():
                                                                     None, kw.get('all_steps', False), kw.get('f32_input', False)),
                             'dtype': DTYPE[prec], 'static_stage_dtype': r['static_dtype'], 'graph_replay': bool(kw.get('graph')),
                             'value': r['value'], 'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': steps, 'warmup': warmup,
-                            'roofline': r['roofline']}
+                            'roofline': r['roofline'],
+                            **{k: r[k] for k in ('static_plan', 'convlstm_winograd', 'held_clock_ghz_after', 'timed_region_s') if k in r}}
                 guarded(name, run)
 
+            # the headline workload held for >= 3 s of timed region (MI355X_MICROARCH.md, DVFS give-back: a clock is believed after
+            # >= 2 s of back-to-back load; the headline's own region is steps x ~13 ms)
+            add('C4 per-GPU shard, SUSTAINED: the headline workload for 250 steps (>= 3 s of timed region)', 1024, 2048, 224, 4, 16,
+                args.precision, 250, 5, clock_after=True)
             add('C4 per-GPU shard, fp32 (the 1e-3 parity precision)', 1024, 2048, 224, 4, 16, 'fp32', 3, 1)
             add('C4 per-GPU shard, bf16 in BOTH stages (static stage bf16 instead of fp16)', 1024, 2048, 224, 4, 16, 'bf16', 3, 1,
                 static_precision='bf16')
@@ -668,6 +711,10 @@ def main():
             add('C2: one frame (6 faces), fp32, static path only, hipGraph replay', 1024, 2048, 224, 1, 1, 'fp32', 20, 5,
                 static_only=True, graph=True)
             add('C5 per-GPU shard: one 16-frame 2048x4096 clip, 6x512^2 faces, fp16', 2048, 4096, 512, 1, 16, 'fp16', 3, 1)
+            # "C2 ... cd = 256 optional variant" (the reference's own smoke-test size, model/cube_pad.py:256-261): layer4 is
+            # 8x8, the map 16x32; no fused static-stage kernel is specialised to it (static_plan says which path every layer takes)
+            add('cube 256 variant: 4 clips x 16 frames 1024x2048, 6x256^2 faces -> 8x8 -> 16x32 map', 1024, 2048, 256, 4, 16,
+                args.precision, 5, 2, want_plan=True)
             add('C4 per-GPU shard, frames resident as f32 [0,1] instead of u8 (SURVEY 8(d) fp32-input variant)',
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
             add('C4 per-GPU shard, return_all_steps: a map after every ConvLSTM step ([4, 16, 14, 28])',

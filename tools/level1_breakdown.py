@@ -1,5 +1,6 @@
 """Where one Level-1 static frame (dataset_feat_extractor.py:142-162 on the shims, 1024x2048, cube 224, fp32) spends its
-time on the GPU box: host conversions, PCIe copies and device work, piece by piece (each piece synchronised)."""
+time on the GPU box: host conversions, PCIe copies and device work, piece by piece (each piece synchronised).
+``--temporal``: the same for one Level-1 temporal window (test_temporal.py:63-85 on the shims, seq_len 5, fp32)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,13 +14,6 @@ from cp_360_weakly_supervised_saliency_amd.utils import synth
 
 dev = 'cuda'
 H, W, cd = 1024, 2048, 224
-rs = synth.resnet50_state(seed=1)
-model = resnet50(precision='fp32')
-model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}, strict=False)
-model = model.to(dev).eval()
-frame = synth.frame_u8(31, H, W)
-input_img = np.array(frame) / 255.0
-e2c = Equi2Cube(cd, input_img, device=dev)
 
 
 def t(fn, n=10):
@@ -29,6 +23,69 @@ def t(fn, n=10):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
+
+
+def temporal():
+    """test_temporal.py:63-85 piece by piece: what is the reference's own loop (host numpy, one pageable H2D per tensor), what
+    is the shim (layout conversions, buffers) and what is device work."""
+    from cp_360_weakly_supervised_saliency_amd.model.clstm import ConvLSTMCell
+    from cp_360_weakly_supervised_saliency_amd.utils.cube_to_equi import Cube2Equi
+    T = 5
+    cs = synth.clstm_state(seed=2)
+    cell = ConvLSTMCell(1000, 1000, precision='fp32')
+    cell.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in cs.items()})
+    cell = cell.to(dev).eval()
+    c2e = Cube2Equi(7, device=dev)
+    subseq = [f for f in synth.cam_clip(6005, T)]
+
+    def window():
+        mx, mn = np.max(subseq), np.min(subseq)
+        init = (subseq[0] - mn) / (mx - mn)
+        cst = torch.FloatTensor(init).to(dev)
+        hidden = torch.FloatTensor(init).to(dev)
+        for f in subseq:
+            f = torch.FloatTensor((f - mn) / (mx - mn)).to(dev)
+            hidden, cst = cell(f, [hidden, cst])
+        return torch.squeeze(torch.max(c2e.to_equi_nn(hidden), 1)[0]).cpu().numpy()
+
+    print('threads: torch %d, cpu_count %d' % (torch.get_num_threads(), os.cpu_count()))
+    print('one window end to end (reference loop)          %.2f ms' % t(window))
+    print('REFERENCE LOOP (host):')
+    print('  np.max + np.min over the 5 frames             %.2f ms' % t(lambda: (np.max(subseq), np.min(subseq))))
+    mx, mn = np.max(subseq), np.min(subseq)
+    print('  (f - mn) / (mx - mn) x 6 (numpy, f32)         %.2f ms' % t(lambda: [(f - mn) / (mx - mn) for f in [subseq[0]] + subseq]))
+    nf = [(f - mn) / (mx - mn) for f in subseq]
+    print('  torch.FloatTensor(ndarray) x 7 (host copy)    %.2f ms' % t(lambda: [torch.FloatTensor(nf[0]) for _ in range(7)]))
+    ft = [torch.FloatTensor(f) for f in nf]
+    print('  .to(dev) x 7 (pageable H2D, 1.2 MB each)      %.2f ms' % t(lambda: [ft[0].to(dev) for _ in range(7)]))
+    x = ft[0].to(dev)
+    h, c = x.clone(), x.clone()
+    print('SHIM (ConvLSTMCell.forward, per call; x 5 per window):')
+    print('  forward() whole                               %.2f ms' % t(lambda: cell(x, [h, c])))
+    n6, cin, w = x.shape[0], x.shape[1], x.shape[2]
+    xh = torch.empty((n6, w, w, 2 * cin), dtype=torch.float32, device=dev)
+    print('  NCHW -> NHWC of x, h, c (3 launches)          %.2f ms' % t(lambda: (ops.nchw_to_nhwc(x, out=xh, coff=0), ops.nchw_to_nhwc(h, out=xh, coff=cin), ops.nchw_to_nhwc(c))))
+    cp = ops.nchw_to_nhwc(c)
+    cn, hf = torch.empty_like(cp), torch.empty_like(cp)
+    print('  allocations (xh, c_next, h_f32)               %.2f ms' % t(lambda: (torch.empty_like(xh), torch.empty_like(cp), torch.empty_like(cp))))
+    with torch.no_grad():
+        print('  cell update on the device (step_nhwc)         %.2f ms' % t(lambda: cell.step_nhwc(xh, cp, cn, hf)))
+    print('  NHWC -> NCHW of hidden, cell (2 launches)     %.2f ms' % t(lambda: (ops.nhwc_to_nchw(hf), ops.nhwc_to_nchw(cn))))
+    hid = ops.nhwc_to_nchw(hf)
+    print('OUTPUT: to_equi_nn + torch.max + squeeze + D2H  %.2f ms' % t(lambda: torch.squeeze(torch.max(c2e.to_equi_nn(hid), 1)[0]).cpu().numpy()))
+
+
+if '--temporal' in sys.argv:
+    temporal()
+    sys.exit(0)
+
+rs = synth.resnet50_state(seed=1)
+model = resnet50(precision='fp32')
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in rs.items()}, strict=False)
+model = model.to(dev).eval()
+frame = synth.frame_u8(31, H, W)
+input_img = np.array(frame) / 255.0
+e2c = Equi2Cube(cd, input_img, device=dev)
 
 
 def norm_batch(cubes):

@@ -16,4 +16,4 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VA
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/wino_probe.py --iters 2 "$@" > $OUT/p$i.log 2>&1
 done
 cd $R
-python3 $R/tools/pmc_wino_summary.py $OUT "$TXT" wino_gemm
+python3 $R/tools/pmc_wino_summary.py $OUT "$TXT" wino_gemm $R/gpurun_out/pmc_clock_bf16_b4_w7.json

@@ -1,7 +1,7 @@
 """Per-launch averages of the counter passes tools/pmc_wino.sh collected for one kernel (name substring = argv[3]) and the
 ratios DESIGN.md quotes (units as in tools/pmc_clip_summary.py).
 
-    python3 tools/pmc_wino_summary.py gpurun_out/pmc_wino profiles/r05_pmc_wino.txt wino_gemm [mfma_cycles_per_simd]
+    python3 tools/pmc_wino_summary.py gpurun_out/pmc_wino profiles/r05_pmc_wino.txt wino_gemm [profiles/pmc_clock_bf16_b4_w7.json]
 """
 import collections, csv, glob, os, sys
 
@@ -47,6 +47,10 @@ def main():
               % ((2 * g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024 / 1e6, 2 * g('FETCH_SIZE') * 1024 / 1e6, g('WRITE_SIZE') * 1024 / 1e6)]
     open(txt, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
+    if len(sys.argv) > 4:      # the clock / pipe-busy pair bench.py quotes next to its register-only clock probe
+        import json
+        json.dump({'kernel': name, 'clock_ghz': round(kcyc / us / 1e3, 3), 'mfma_pipe_busy': round(mfma / kcyc, 3), 'launch_us': round(us, 1),
+                   'source': os.path.basename(txt)}, open(sys.argv[4], 'w'), indent=1)
 
 
 if __name__ == '__main__':
