@@ -891,7 +891,7 @@ struct WindowWs {
 };
 
 bool window_batches_x(const CClstm& Cl, int n_clips) {
-    // Opt-in (CP360_XBATCH=1; measured performance-neutral): it changes Conv1's accumulation order, so
+    // Opt-in (CP360_XBATCH=1; measured performance-neutral, docs/rounds/r01-r04_design.md section 3): it changes Conv1's accumulation order, so
     // the default window issues exactly the launches of T cp360_clstm_step calls and gives the same bits
     static const int env = []() { const char* e = getenv("CP360_XBATCH"); return e ? atoi(e) : 0; }();
     (void)n_clips;
