@@ -345,38 +345,39 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, 
         *reinterpret_cast<u32x4*>(patch + pix * 128 + ch * 16) = val;
     }
     __syncthreads();
-    const int tpf = th * th;
-    for (int it = threadIdx.x; it < tpf * 8; it += 256) {
-        const int tile = it >> 3, ch = it & 7;
+    // items = (row i of V, tile, 16-byte chunk): 4 x th^2 x 8 of them, i outermost so that the lanes of a wave store neighbouring tiles
+    // of one position (8 tiles x 64 B contiguous per sub-step and store instruction)
+    const int tpf = th * th, per_row = tpf * 8;
+    const size_t pstride = (size_t)nsub * m_pad * 32;
+    for (int it = threadIdx.x; it < 4 * per_row; it += 256) {
+        const int i = it / per_row, r = it - i * per_row;
+        const int tile = r >> 3, ch = r & 7;
         const int sub = cb * 2 + (ch >> 2);
         if (sub >= nsub) continue;
         const int ty = tile / th, tx = tile - ty * th;
         const unsigned char* base = patch + ((2 * ty) * pw + 2 * tx) * 128 + ch * 16;
-        T* dst = v + ((size_t)sub * m_pad + (size_t)img * tpf + tile) * 32 + (ch & 3) * 8;
-        const size_t pstride = (size_t)nsub * m_pad * 32;
+        T* dst = v + ((size_t)sub * m_pad + (size_t)img * tpf + tile) * 32 + (ch & 3) * 8 + (size_t)(i * 4) * pstride;
+        // e[c] = (B^T d)[i][c]: rows (0 - 2), (1 + 2), (2 - 1), (1 - 3) of the window
+        const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+        float e[4][8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                              // row i of V: e[c] = (B^T d)[i][c]
-            const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
-            float e[4][8];
+        for (int c = 0; c < 4; ++c) {
+            float da[8], db[8];
+            unpack8(*reinterpret_cast<const u32x4*>(base + (ra * pw + c) * 128), da, T());
+            unpack8(*reinterpret_cast<const u32x4*>(base + (rb * pw + c) * 128), db, T());
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float da[8], db[8];
-                unpack8(*reinterpret_cast<const u32x4*>(base + (ra * pw + c) * 128), da, T());
-                unpack8(*reinterpret_cast<const u32x4*>(base + (rb * pw + c) * 128), db, T());
-#pragma unroll
-                for (int k = 0; k < 8; ++k) e[c][k] = i == 1 ? da[k] + db[k] : da[k] - db[k];
-            }
-            float o[4][8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                o[0][k] = e[0][k] - e[2][k];
-                o[1][k] = e[1][k] + e[2][k];
-                o[2][k] = e[2][k] - e[1][k];
-                o[3][k] = e[1][k] - e[3][k];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)(i * 4 + j) * pstride) = pack8(o[j], T());
+            for (int k = 0; k < 8; ++k) e[c][k] = i == 1 ? da[k] + db[k] : da[k] - db[k];
         }
+        float o[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o[0][k] = e[0][k] - e[2][k];
+            o[1][k] = e[1][k] + e[2][k];
+            o[2][k] = e[2][k] - e[1][k];
+            o[3][k] = e[1][k] - e[3][k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)j * pstride) = pack8(o[j], T());
     }
 }
 
