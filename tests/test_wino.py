@@ -138,3 +138,74 @@ def test_wino_gates_matches_torch_cpu(n, prec):
     assert np.max(np.abs(xhc[..., Hc:].transpose(0, 3, 1, 2) - got_h)) <= (8e-3 if prec == 'bf16' else 1e-3)   # h half = rounded h
     xn = (cam[:, 1] - mm[:, :1, None]) / (mm[:, 1:, None] - mm[:, :1, None])                                    # [B, P, Hc]
     assert np.max(np.abs(xhc[..., :Hc].reshape(B, P, Hc) - xn)) <= (4e-3 if prec == 'bf16' else 5e-4)
+
+
+# ------------------------------------------------------------------ the cell in the Winograd domain
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec,w,B', [('bf16', 7, 4), ('bf16', 8, 4), ('fp16', 16, 1)])
+def test_wino_cell_window_matches_oracle(prec, w, B):
+    """A whole window (test_temporal.py:63-85: min / max, hidden = cell = frame 0, T updates, cube -> equi, channel max) for the
+    launch shapes the planner runs in the Winograd domain - 4 clips of 7x7 faces (BASELINE C4's shard), 4 clips of 8x8 faces
+    (cube 256), one clip of 16x16 faces (C5's shard) - against the oracle's window on every clip."""
+    from oracle import o_clstm
+    from cp_360_weakly_supervised_saliency_amd.model.clstm import ConvLSTMCell
+    from cp_360_weakly_supervised_saliency_amd.temporal_model.test_temporal import ClipRunner
+    from cp_360_weakly_supervised_saliency_amd.utils.cube_to_equi import Cube2Equi
+    from cp_360_weakly_supervised_saliency_amd.utils import synth
+    sd = synth.clstm_state(seed=2)
+    cell = ConvLSTMCell(1000, 1000, precision=prec)
+    cell.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    cell = cell.to(DEV).eval()
+    assert cell.uses_winograd(6 * B, w)
+    T, P = 3, 6 * w * w
+    cams = [synth.cam_clip(7700 + 10 * w + b, T, w=w) for b in range(B)]
+    pack = lambda f: np.ascontiguousarray(f.transpose(0, 1, 3, 4, 2)).reshape(T, P, 1000)
+    sal = ClipRunner(cell, Cube2Equi(w), B, T, w).run(torch.from_numpy(np.stack([pack(f) for f in cams])).to(DEV)).cpu().numpy()
+    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+    tol = 3e-3 if prec == 'bf16' else 6e-4                      # measured 1.1e-3 / 2.0e-4
+    for b in range(B):
+        want = o_clstm.window_saliency(cams[b], sdt)
+        err = float(np.max(np.abs(sal[b] - want)))
+        print('wino cell %s w=%d clip %d: map max|d| %.2e (range %.3f..%.3f)' % (prec, w, b, err, want.min(), want.max()))
+        assert err <= tol, (b, err)
+
+
+@pytest.mark.gpu
+def test_clstm_wino_lazy_load_through_the_c_abi():
+    """INTEGRATION.md's two-line binder change with raw ctypes: cp360_clstm_wino_state says 2 for a shape that would run in the
+    Winograd domain, the step runs on the direct kernels until cp360_clstm_load_wino has packed U, then in the Winograd domain
+    (state 1, another workspace size) - the two results agree within the 16-bit rounding; one clip stays direct (state 0)."""
+    L = _lib.lib()
+    dt, code = torch.bfloat16, _lib.BF16
+    Cin = Hc = 256
+    B, w = 4, 7
+    n6, c4 = 6 * B, 4 * Hc
+    g = lambda seed, shape, std: torch.from_numpy(hashrng.normal(seed, shape, 0, std)).to(DEV)
+    w1, w2, wg = g(7801, (c4, Cin + Hc, 3, 3), (2.0 / (9 * c4)) ** 0.5), g(7802, (c4, c4, 3, 3), (2.0 / (9 * c4)) ** 0.5), \
+        g(7803, (c4, c4, 3, 3), (2.0 / (9 * c4)) ** 0.5)
+    b1, b2, bg = g(7804, (c4,), 0.05), g(7805, (c4,), 0.05), g(7806, (c4,), 0.05)
+    h = C.c_void_p()
+    _lib.check(L.cp360_create(torch.cuda.current_device(), C.byref(h)))
+    try:
+        p = _lib.ptr
+        _lib.check(L.cp360_clstm_load(h, code, p(w1), p(b1), p(w2), p(b2), p(wg), p(bg), Cin, Hc, w, _lib.stream()))
+        assert L.cp360_clstm_wino_state(h, 1, w) == 0 and L.cp360_clstm_wino_state(h, B, w) == 2
+        outs, sizes = [], []
+        for phase in range(2):
+            if phase == 1:
+                _lib.check(L.cp360_clstm_load_wino(h, p(w1), p(w2), p(wg), _lib.stream()))
+                assert L.cp360_clstm_wino_state(h, B, w) == 1
+            nb = L.cp360_clstm_workspace_bytes(h, B, w)
+            sizes.append(nb)
+            ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            xh = torch.from_numpy(hashrng.uniform(7810, (n6, w, w, Cin + Hc), 0.0, 1.0)).to(DEV).to(dt)
+            c0 = torch.from_numpy(hashrng.uniform(7811, (n6, w, w, Hc), 0.0, 1.0)).to(DEV)
+            c1, hf = torch.empty_like(c0), torch.empty_like(c0)
+            _lib.check(L.cp360_clstm_step(h, p(xh), p(c0), p(c1), p(hf), B, w, None, None, 0, p(ws), nb, _lib.stream()))
+            torch.cuda.synchronize()
+            outs.append((c1.cpu().numpy(), hf.cpu().numpy()))
+        assert min(sizes) > 0                                      # (V + M workspaces replace the split-K slabs: query again after the load)
+        for a, b in zip(outs[0], outs[1]):
+            assert np.all(np.isfinite(a)) and np.max(np.abs(a - b)) <= 2e-2 and not np.array_equal(a, b)
+    finally:
+        L.cp360_destroy(h)
