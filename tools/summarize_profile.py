@@ -58,9 +58,9 @@ def main():
         # channels x 16 positions for Conv2 / Gates, K = 2000 for Conv1)
         wino = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if 'wino_gemm' in r['Kernel_Name']]
         if wino:
-            cut = 0.75 * max(wino)
-            big = [d for d in wino if d >= cut]
-            small = [d for d in wino if d < cut]
+            # two of a cell update's three GEMMs are K = 4000 (Conv2, Gates), one is K = 2000 (Conv1): the longer two thirds
+            wino.sort()
+            small, big = wino[: len(wino) // 3], wino[len(wino) // 3:]
             lines.append('')
             lines.append('wino_gemm_kernel launches: %d of K = 4000 x 16 positions (ConvLSTM Conv2 / Gates in the Winograd domain, the dominant '
                          'kernel of bench.py): avg %.1f us; %d shorter ones (Conv1, K = 2000): avg %.1f us'
