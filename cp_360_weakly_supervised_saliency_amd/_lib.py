@@ -45,7 +45,7 @@ PUBLIC_SYMBOLS = [
     'cp360_clstm_window_workspace_bytes', 'cp360_clstm_window', 'cp360_clock_probe', 'cp360_conv_prefer_clip',
     'cp360_conv_plan_describe', 'cp360_resnet_plan_describe', 'cp360_wino_packed_bytes', 'cp360_wino_v_bytes',
     'cp360_wino_m_bytes', 'cp360_wino_preferred', 'cp360_wino_pack_weights', 'cp360_wino_input', 'cp360_wino_gemm',
-    'cp360_wino_output', 'cp360_wino_output_gates', 'cp360_wino_forward', 'cp360_clstm_wino_state', 'cp360_clstm_load_wino',
+    'cp360_wino_output', 'cp360_wino_output_gates', 'cp360_wino_forward', 'cp360_wino_output_input', 'cp360_clstm_wino_state', 'cp360_clstm_load_wino',
 ]
 # ... and of include/cp360_internal.h: the shape-specific fused kernels the stage contexts are built from (exported for
 # tests and the CP360_CTX=0 planner; not part of the boundary)
@@ -201,6 +201,7 @@ def lib():
     L.cp360_wino_input.argtypes = [pw, vp, vp, vp]
     L.cp360_wino_gemm.argtypes = [pw, vp, vp, vp, vp]
     L.cp360_wino_output.argtypes = [pw, vp, vp, vp, vp]
+    L.cp360_wino_output_input.argtypes = [pw, vp, vp, vp, vp]
     L.cp360_wino_output_gates.argtypes = [pw, vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, sz, vp]
     L.cp360_wino_forward.argtypes = [pw, vp, vp, vp, vp, vp, vp, vp]
     L.cp360_wino_gemm_raw.argtypes = [i, vp, vp, vp, i, i, i, i, i, vp]

@@ -838,9 +838,23 @@ int clstm_run(cp360_ctx* ctx, bool dry, void* xh, const float* c_prev, float* c_
         if (ws_bytes < w.total()) return CP360_ERR_BAD_SHAPE;
         unsigned char* v = ws + 2 * w.act;
         float* m = (float*)(ws + 2 * w.act + w.wv);
-        if ((rc = cp360_wino_forward(&d1, xh, Cl.u1, Cl.c1.bias, a1, v, m, st))) return rc;
-        if ((rc = cp360_wino_forward(&d2, a1, Cl.u2, Cl.c2.bias, a2, v, m, st))) return rc;
-        if ((rc = cp360_wino_input(&dg, a2, v, st))) return rc;
+        // between two convolutions the output transform of one and the input transform of the next are ONE launch (faces up to
+        // 9 x 9: cp360_wino_output_input; larger faces: the two launches through the activation buffers a1 / a2)
+        if ((rc = cp360_wino_input(&d1, xh, v, st))) return rc;
+        if ((rc = cp360_wino_gemm(&d1, v, Cl.u1, m, st))) return rc;
+        rc = cp360_wino_output_input(&d1, m, Cl.c1.bias, v, st);
+        if (rc == CP360_ERR_UNSUPPORTED) {
+            if ((rc = cp360_wino_output(&d1, m, Cl.c1.bias, a1, st))) return rc;
+            rc = cp360_wino_input(&d2, a1, v, st);
+        }
+        if (rc) return rc;
+        if ((rc = cp360_wino_gemm(&d2, v, Cl.u2, m, st))) return rc;
+        rc = cp360_wino_output_input(&d2, m, Cl.c2.bias, v, st);
+        if (rc == CP360_ERR_UNSUPPORTED) {
+            if ((rc = cp360_wino_output(&d2, m, Cl.c2.bias, a2, st))) return rc;
+            rc = cp360_wino_input(&dg, a2, v, st);
+        }
+        if (rc) return rc;
         if ((rc = cp360_wino_gemm(&dg, v, Cl.ug, m, st))) return rc;
         return cp360_wino_output_gates(&dg, m, Cl.gbias, c_prev, c_next, xh, Cl.cin + Cl.ch, Cl.cin, h_f32, x_next, minmax, 0,
                                        clip_stride, st);

@@ -433,6 +433,86 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     }
 }
 
+// Output transform of one convolution AND the input transform of the next in one launch (faces small enough that a cube's
+// activations of a 32-channel block fit in LDS: w <= 9): a workgroup = (cube, 32 channels = one K sub-step of the next GEMM).
+// Phase 1: every (tile, 4-channel group) item reads its 16 positions of M, transforms, adds bias, applies ReLU, rounds to T and puts
+// the tile's pixels into the LDS image of the cube; phase 2: every (V row i, tile, 8-channel chunk) item gathers its 4 x 4 window from
+// that image through a CubePad(1) source table and stores four positions of the next convolution's V.  The values are exactly those
+// of wino_out_kernel + wino_in_kernel (same roundings) - the 16-bit activation tensor just never goes through memory, and the
+// 49 MB of V writes overlap the 98 MB of M reads instead of following them in a second launch.
+template <typename T>
+__global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+                                                          T* __restrict__ v, int w, int th, int c_out, int ldm, int m_pad, int relu,
+                                                          int nsub) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int cube = blockIdx.x / nsub, cb = blockIdx.x - cube * nsub;
+    const int ww = w * w, P = 6 * ww, tpf = th * th, pw = 2 * th + 2, wp = w + 2, pp = pw * pw;
+    unsigned char* act = sm;                                               // [P][64 B]
+    unsigned short* tab = reinterpret_cast<unsigned short*>(sm + ((P * 64 + 15) & ~15));   // [6][pw][pw]: pixel of the cube, 0xffff = zero
+    const CubePadGeom geom{w, 1, 1, 1, 1};
+    for (int i = threadIdx.x; i < 6 * pp; i += blockDim.x) {
+        const int f = i / pp, r = i - f * pp, py = r / pw, px = r - py * pw;
+        tab[i] = (py < wp && px < wp) ? (unsigned short)cubepad_src(f, py, px, geom) : (unsigned short)0xffff;
+    }
+    const size_t pstride = (size_t)m_pad * ldm;
+    for (int it = threadIdx.x; it < 6 * tpf * 8; it += blockDim.x) {
+        const int tl = it >> 3, g = it & 7, c = cb * 32 + g * 4;
+        f32x4 y[4];
+        f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < c_out) {
+            f32x4 mm[16];
+            load_positions(m, pstride, (unsigned)(((cube * 6 * tpf + tl) * ldm + c) * 4), mm);
+            if (bias) bb = *reinterpret_cast<const f32x4*>(bias + c);
+            out_transform(mm, y);
+        } else {                                                           // channels past c_out: the next V's zero padding
+            y[0] = y[1] = y[2] = y[3] = bb;
+        }
+        const int f = tl / tpf, t = tl - f * tpf, ty = t / th, tx = t - ty * th;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
+            if (oy >= w || ox >= w) continue;
+            float o[4] = {y[q][0] + bb[0], y[q][1] + bb[1], y[q][2] + bb[2], y[q][3] + bb[3]};
+            if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+            store4(reinterpret_cast<T*>(act + (f * ww + oy * w + ox) * 64) + g * 4, o);
+        }
+    }
+    __syncthreads();
+    const int per_row = 6 * tpf * 4;
+    const size_t vps = (size_t)nsub * m_pad * 32;                          // elements between two positions of V
+    for (int it = threadIdx.x; it < 4 * per_row; it += blockDim.x) {
+        const int i = it / per_row, r = it - i * per_row;
+        const int tl = r >> 2, ch = r & 3;
+        const int f = tl / tpf, t = tl - f * tpf, ty = t / th, tx = t - ty * th;
+        const unsigned short* tb = tab + f * pp + (2 * ty) * pw + 2 * tx;
+        const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+        float e[4][8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned pa = tb[ra * pw + c], pb = tb[rb * pw + c];
+            const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+            const u32x4 xa = pa == 0xffffu ? z : *reinterpret_cast<const u32x4*>(act + pa * 64 + ch * 16);
+            const u32x4 xb = pb == 0xffffu ? z : *reinterpret_cast<const u32x4*>(act + pb * 64 + ch * 16);
+            float da[8], db[8];
+            unpack8(xa, da, T());
+            unpack8(xb, db, T());
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[c][k] = i == 1 ? da[k] + db[k] : da[k] - db[k];
+        }
+        float o[4][8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            o[0][k] = e[0][k] - e[2][k];
+            o[1][k] = e[1][k] + e[2][k];
+            o[2][k] = e[2][k] - e[1][k];
+            o[3][k] = e[1][k] - e[3][k];
+        }
+        T* dst = v + (size_t)(i * 4) * vps + ((size_t)cb * m_pad + (size_t)cube * 6 * tpf + tl) * 32 + ch * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)j * vps) = pack8(o[j], T());
+    }
+}
+
 // The Gates convolution's output transform + the cell update of model/clstm.py:68-80 (gate order in, remember, out, cell),
 // with the optional window normalisation of the NEXT frame into the x half (as lstm_gates_kernel, conv_igemm.hip).
 __device__ __forceinline__ float wsigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -615,6 +695,31 @@ extern "C" int cp360_wino_output(const cp360_wino_desc* d, const float* m, const
     else
         hipLaunchKernelGGL((wino_out_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (bf16_raw*)out, g.tiles, d->face, g.th,
                            d->c_out, g.ldm, g.m_pad, ld_out, d->out_coff, d->relu);
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+// cp360_wino_output of THIS convolution fused with cp360_wino_input of the NEXT one (same faces, next c_in = this c_out, dense
+// pixels): v_next receives what cp360_wino_input would make of this convolution's output - same bits, no activation tensor.
+// CP360_ERR_UNSUPPORTED for faces above 9 x 9 (the cube's 32-channel image no longer fits the LDS budget that keeps two
+// workgroups per CU): the caller then runs the two kernels.
+extern "C" int cp360_wino_output_input(const cp360_wino_desc* d, const float* m, const float* bias, void* v_next, void* stream) {
+    WinoGeom g;
+    int rc = wino_check(d, &g);
+    if (rc) return rc;
+    if (!m || !v_next) return CP360_ERR_NULL;
+    const int pw = 2 * g.th + 2, P = 6 * d->face * d->face;
+    const size_t lds = (size_t)((P * 64 + 15) & ~15) + (size_t)6 * pw * pw * 2;
+    if (d->face > 9 || lds > 40 * 1024) return CP360_ERR_UNSUPPORTED;
+    const int nsub = (d->c_out + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((d->n_img / 6) * nsub));
+    if (d->dtype == CP360_F16)
+        hipLaunchKernelGGL((wino_out_in_kernel<f16_raw>), grid, dim3(768), lds, st, m, bias, (f16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
+                           g.m_pad, d->relu, nsub);
+    else
+        hipLaunchKernelGGL((wino_out_in_kernel<bf16_raw>), grid, dim3(768), lds, st, m, bias, (bf16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
+                           g.m_pad, d->relu, nsub);
     CP360_CHECK_HIP();
     return CP360_OK;
 }

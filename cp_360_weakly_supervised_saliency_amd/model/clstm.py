@@ -108,9 +108,19 @@ class ConvLSTMCell(nn.Module):
         # x_next = (cam, minmax, P, clip_stride, t_next): the gate kernel also writes the next step's normalised input
         xn = None if x_next is None else (x_next[0], x_next[1], 0, x_next[2], x_next[3], x_next[4])
         if self.uses_winograd(n6, w):
-            a1 = p['w1'](xh, out=None if bufs is None else bufs[0])
-            a2 = p['w2'](a1, out=None if bufs is None else bufs[1])
-            p['wg'].gates(a2, p['gbias'], c_prev, c_next, xh, self.input_size, h_f32, x_next=xn)
+            # (the same launches as csrc/ctx.hip's clstm_run: between two convolutions ONE fused output + input transform where
+            # the faces allow it, else the two kernels through an activation buffer)
+            convs = (p['w1'], p['w2'], p['wg'])
+            v, d = convs[0].input(xh)
+            for k in range(2):
+                m = convs[k].gemm(v, d)
+                fused = convs[k].output_input(m, d, convs[k + 1])
+                if fused is None:
+                    a = convs[k].output(m, d, out=None if bufs is None else bufs[k])
+                    fused = convs[k + 1].input(a)
+                v, d = fused
+            m = convs[2].gemm(v, d)
+            convs[2].gates_from(m, d, p['gbias'], c_prev, c_next, xh, self.input_size, h_f32, x_next=xn)
             return
         a1 = p['c1'](xh, out=None if bufs is None else bufs[0])
         a2 = p['c2'](a1, out=None if bufs is None else bufs[1])

@@ -803,37 +803,61 @@ class WinoConv:
                 or x.shape[0] % 6:
             raise ValueError("x must be a contiguous %s [6B, w, w, >= %d] tensor" % (self.dtype, self.c_in))
 
-    def sums(self, x):
-        """Input transform + the 16 GEMMs: returns (M workspace f32 [16, m_pad, c_out], desc) for an output transform."""
+    def input(self, x):
+        """Input transform of x: returns (V workspace, desc)."""
         self._check_in(x)
-        n_img, w = x.shape[0], x.shape[1]
-        d = self.desc(n_img, w, pix_stride=x.shape[3])
-        v, m = self.workspace(d)
+        d = self.desc(x.shape[0], x.shape[1], pix_stride=x.shape[3])
+        v, _ = self.workspace(d)
+        check(lib().cp360_wino_input(C.byref(d), ptr(x), ptr(v), stream()))
+        return v, d
+
+    def gemm(self, v, d):
+        """The 16 GEMMs on a transformed input: returns the M workspace (f32 [16, m_pad, c_out])."""
+        _, m = self.workspace(d)
         L = lib()
-        check(L.cp360_wino_input(C.byref(d), ptr(x), ptr(v), stream()))
         if LAUNCH_TIMER is None:
             check(L.cp360_wino_gemm(C.byref(d), ptr(v), ptr(self.packed), ptr(m), stream()))
         else:
-            flops = 2.0 * n_img * w * w * self.c_out * self.c_in * 9          # quoted on the DIRECT form's flops
+            flops = 2.0 * d.n_img * d.face * d.face * self.c_out * self.c_in * 9       # quoted on the DIRECT form's flops
             packed = self.packed
             check(LAUNCH_TIMER.wrap(self.tag, flops, lambda: L.cp360_wino_gemm(C.byref(d), ptr(v), ptr(packed), ptr(m), stream())))
-        return m, d
+        return m
 
-    def __call__(self, x, out=None, out_coff=0):
-        m, d = self.sums(x)
-        n_img, w = x.shape[0], x.shape[1]
+    def sums(self, x):
+        """Input transform + the 16 GEMMs: returns (M workspace, desc) for an output transform."""
+        v, d = self.input(x)
+        return self.gemm(v, d), d
+
+    def output(self, m, d, out=None, out_coff=0):
+        n_img, w = d.n_img, d.face
         if out is None:
-            out = torch.empty((n_img, w, w, self.c_out), dtype=self.dtype, device=x.device)
+            out = torch.empty((n_img, w, w, self.c_out), dtype=self.dtype, device=self.device)
         require_gpu(out)
         _check_buf('out', out, self.dtype, (n_img, w, w, self.c_out + out_coff))
         d.ld_out, d.out_coff = out.shape[3], out_coff
         check(lib().cp360_wino_output(C.byref(d), ptr(m), ptr(self.bias), ptr(out), stream()))
         return out
 
-    def gates(self, x, bias, c_prev, c_next, h_out, h_coff, h_f32=None, x_next=None):
-        """The Gates convolution + the cell update (clstm.py:68-80) in the output transform; x_next as ops.lstm_gates."""
+    def output_input(self, m, d, nxt):
+        """This convolution's output transform fused with ``nxt``'s input transform (cp360_wino_output_input): returns
+        (V workspace, nxt's desc), or None where the fused kernel does not apply (faces above 9 x 9)."""
+        if nxt.c_in != self.c_out or nxt.dtype != self.dtype:
+            raise ValueError("the next convolution reads this one's output")
+        dn = nxt.desc(d.n_img, d.face)
+        v, _ = self.workspace(dn)
+        rc = lib().cp360_wino_output_input(C.byref(d), ptr(m), ptr(self.bias), ptr(v), stream())
+        if rc == -8:                                           # CP360_ERR_UNSUPPORTED
+            return None
+        check(rc)
+        return v, dn
+
+    def __call__(self, x, out=None, out_coff=0):
         m, d = self.sums(x)
-        n_img, w = x.shape[0], x.shape[1]
+        return self.output(m, d, out, out_coff)
+
+    def gates_from(self, m, d, bias, c_prev, c_next, h_out, h_coff, h_f32=None, x_next=None):
+        """The gate epilogue (clstm.py:68-80) on the Gates convolution's M; x_next as ops.lstm_gates."""
+        n_img, w = d.n_img, d.face
         M, Hc = n_img * w * w, self.c_out // 4
         require_gpu(bias, c_prev, c_next, h_out, h_f32)
         _check_buf('gates bias', bias, torch.float32, numel=4 * Hc)
@@ -851,6 +875,11 @@ class WinoConv:
             xp, mm = C.c_void_p(cam.data_ptr() + 4 * t_next * P * Hc), ptr(minmax)
         check(lib().cp360_wino_output_gates(C.byref(d), ptr(m), ptr(bias), ptr(c_prev), ptr(c_next), ptr(h_out), h_out.shape[-1],
                                             h_coff, ptr(h_f32), xp, mm, x_coff, stride, stream()))
+
+    def gates(self, x, bias, c_prev, c_next, h_out, h_coff, h_f32=None, x_next=None):
+        """The Gates convolution + the cell update (clstm.py:68-80) in the output transform; x_next as ops.lstm_gates."""
+        m, d = self.sums(x)
+        self.gates_from(m, d, bias, c_prev, c_next, h_out, h_coff, h_f32, x_next)
 
 
 def window_minmax(x, B, per_clip, minmax, scratch, clip_stride=0):

@@ -316,6 +316,10 @@ int cp360_wino_output(const cp360_wino_desc* d, const float* m, const float* bia
 int cp360_wino_output_gates(const cp360_wino_desc* d, const float* m, const float* bias, const float* c_prev, float* c_next,
                             void* h_out, int ld_h, int h_coff, float* h_f32, const float* x_next, const float* minmax,
                             int x_coff, size_t clip_stride, void* stream);
+/* cp360_wino_output of THIS convolution fused with cp360_wino_input of the NEXT one (same faces, next c_in = this c_out, dense
+ * pixels): v_next = what cp360_wino_input would make of this convolution's output, bit for bit, in one launch and without the
+ * activation tensor.  Faces up to 9 x 9 (a cube's 32-channel image in LDS); larger: CP360_ERR_UNSUPPORTED, run the two calls. */
+int cp360_wino_output_input(const cp360_wino_desc* d, const float* m, const float* bias, void* v_next, void* stream);
 /* cp360_wino_input + cp360_wino_gemm + cp360_wino_output. */
 int cp360_wino_forward(const cp360_wino_desc* d, const void* in, const void* packed, const float* bias, void* out, void* v,
                        float* m, void* stream);

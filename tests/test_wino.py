@@ -209,3 +209,49 @@ def test_clstm_wino_lazy_load_through_the_c_abi():
             assert np.all(np.isfinite(a)) and np.max(np.abs(a - b)) <= 2e-2 and not np.array_equal(a, b)
     finally:
         L.cp360_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n,n_img', [(7, 24), (8, 12), (5, 6), (7, 30)])
+def test_wino_fused_output_input_equals_the_two_kernels(n, n_img, prec):
+    """cp360_wino_output_input (one launch between two convolutions of the ConvLSTM) against cp360_wino_output followed by
+    cp360_wino_input: the same V, bit for bit, on every valid tile row - c_out = 264 ends inside a 32-channel block (the
+    next V's zero padding), 30 faces span two 384-row tile blocks; 16x16 faces are refused (the caller runs the two kernels)."""
+    dt = _TDT[prec]
+    cin, cmid, cout = 40, 264, 64
+    x = hashrng.normal(7900 + n, (n_img, cin, n, n))
+    w1 = hashrng.normal(7901, (cmid, cin, 3, 3), 0, (2.0 / (9 * cin)) ** 0.5)
+    b1 = hashrng.normal(7902, (cmid,), 0, 0.1)
+    w2 = hashrng.normal(7903, (cout, cmid, 3, 3), 0, (2.0 / (9 * cmid)) ** 0.5)
+    c1 = ops.WinoConv(torch.from_numpy(w1), torch.from_numpy(b1), True, dt, DEV)
+    c2 = ops.WinoConv(torch.from_numpy(w2), None, False, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    m, d = c1.sums(xt)
+    m = m.clone()                                                      # (the M workspace is shared; keep this convolution's sums)
+    th = (n + 1) // 2
+    tiles, nsub = n_img * th * th, (cmid + 31) // 32
+    m_pad = -(-tiles // 384) * 384
+    view = lambda v: v[: 16 * nsub * m_pad * 64].view(dt).view(16, nsub, m_pad, 32)[:, :, :tiles].clone()
+    a1 = c1.output(m, d)
+    v_two, _ = c2.input(a1)
+    want = view(v_two)
+    v_two.zero_()
+    v_one, d2 = c1.output_input(m, c1.desc(n_img, n), c2)
+    got = view(v_one)
+    assert d2.c_in == cmid and torch.equal(got, want)
+    assert float(want.float().abs().max()) > 0.1 and bool((want[:, -1, :, 8:] == 0).all())     # channels 264 .. 287 of the last block: zeros
+    # and the convolution that follows gives the torch-CPU result of conv2(relu(conv1(x)))
+    y = ops.nhwc_to_nchw(c2.output(c2.gemm(v_one, d2), d2), out_dtype=torch.float32).cpu().numpy()
+    mid = _ref(x, w1, b1, dt, True)
+    ref = _ref(_rb(mid, dt).numpy(), w2, np.zeros(cout, np.float32), dt, False)
+    mx, rms = _errs(y, ref)
+    assert mx <= 2 * _TOL[prec] and rms <= 2 * _RMS[prec], (mx, rms)
+
+
+@pytest.mark.gpu
+def test_wino_fused_output_input_refuses_large_faces():
+    c1 = ops.WinoConv(torch.zeros(32, 32, 3, 3), None, False, torch.float16, DEV)
+    xt = torch.zeros((6, 16, 16, 32), dtype=torch.float16, device=DEV)
+    m, d = c1.sums(xt)
+    assert c1.output_input(m, d, c1) is None
