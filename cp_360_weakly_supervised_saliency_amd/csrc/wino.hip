@@ -440,23 +440,26 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // that image through a CubePad(1) source table and stores four positions of the next convolution's V.  The values are exactly those
 // of wino_out_kernel + wino_in_kernel (same roundings) - the 16-bit activation tensor just never goes through memory, and the
 // 49 MB of V writes overlap the 98 MB of M reads instead of following them in a second launch.
-template <typename T>
+// CB = channels per workgroup: 32 (one K sub-step of the next GEMM; faces up to 9 x 9).  (CB = 16 - half a sub-step, for 16 x 16 faces,
+// where a cube's image of 32 channels would be 98 KB of LDS - works and is slower than the two kernels: see the launcher.)
+template <typename T, int CB>
 __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                           T* __restrict__ v, int w, int th, int c_out, int ldm, int m_pad, int relu,
-                                                          int nsub) {
+                                                          int nsub, int nblk) {
+    constexpr int ROW = CB * 2, NG = CB / 4, NCH = CB / 8;                // bytes per pixel of the image, 4-channel groups, 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const int cube = blockIdx.x / nsub, cb = blockIdx.x - cube * nsub;
+    const int cube = blockIdx.x / nblk, cb = blockIdx.x - cube * nblk;
     const int ww = w * w, P = 6 * ww, tpf = th * th, pw = 2 * th + 2, wp = w + 2, pp = pw * pw;
-    unsigned char* act = sm;                                               // [P][64 B]
-    unsigned short* tab = reinterpret_cast<unsigned short*>(sm + ((P * 64 + 15) & ~15));   // [6][pw][pw]: pixel of the cube, 0xffff = zero
+    unsigned char* act = sm;                                               // [P][ROW]
+    unsigned short* tab = reinterpret_cast<unsigned short*>(sm + ((P * ROW + 15) & ~15));   // [6][pw][pw]: pixel of the cube, 0xffff = zero
     const CubePadGeom geom{w, 1, 1, 1, 1};
     for (int i = threadIdx.x; i < 6 * pp; i += blockDim.x) {
         const int f = i / pp, r = i - f * pp, py = r / pw, px = r - py * pw;
         tab[i] = (py < wp && px < wp) ? (unsigned short)cubepad_src(f, py, px, geom) : (unsigned short)0xffff;
     }
     const size_t pstride = (size_t)m_pad * ldm;
-    for (int it = threadIdx.x; it < 6 * tpf * 8; it += blockDim.x) {
-        const int tl = it >> 3, g = it & 7, c = cb * 32 + g * 4;
+    for (int it = threadIdx.x; it < 6 * tpf * NG; it += blockDim.x) {
+        const int tl = it / NG, g = it - tl * NG, c = cb * CB + g * 4;
         f32x4 y[4];
         f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < c_out) {
@@ -474,15 +477,16 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
             if (oy >= w || ox >= w) continue;
             float o[4] = {y[q][0] + bb[0], y[q][1] + bb[1], y[q][2] + bb[2], y[q][3] + bb[3]};
             if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
-            store4(reinterpret_cast<T*>(act + (f * ww + oy * w + ox) * 64) + g * 4, o);
+            store4(reinterpret_cast<T*>(act + (f * ww + oy * w + ox) * ROW) + g * 4, o);
         }
     }
     __syncthreads();
-    const int per_row = 6 * tpf * 4;
+    const int per_row = 6 * tpf * NCH;
     const size_t vps = (size_t)nsub * m_pad * 32;                          // elements between two positions of V
+    const int sub = (cb * CB) >> 5, coff = (cb * CB) & 31;                 // this block's place inside the 32-channel rows of V
     for (int it = threadIdx.x; it < 4 * per_row; it += blockDim.x) {
         const int i = it / per_row, r = it - i * per_row;
-        const int tl = r >> 2, ch = r & 3;
+        const int tl = r / NCH, ch = r - tl * NCH;
         const int f = tl / tpf, t = tl - f * tpf, ty = t / th, tx = t - ty * th;
         const unsigned short* tb = tab + f * pp + (2 * ty) * pw + 2 * tx;
         const int ra = i == 0 ? 0 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
@@ -491,8 +495,8 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
         for (int c = 0; c < 4; ++c) {
             const unsigned pa = tb[ra * pw + c], pb = tb[rb * pw + c];
             const u32x4 z = u32x4{0u, 0u, 0u, 0u};
-            const u32x4 xa = pa == 0xffffu ? z : *reinterpret_cast<const u32x4*>(act + pa * 64 + ch * 16);
-            const u32x4 xb = pb == 0xffffu ? z : *reinterpret_cast<const u32x4*>(act + pb * 64 + ch * 16);
+            const u32x4 xa = pa == 0xffffu ? z : *reinterpret_cast<const u32x4*>(act + pa * ROW + ch * 16);
+            const u32x4 xb = pb == 0xffffu ? z : *reinterpret_cast<const u32x4*>(act + pb * ROW + ch * 16);
             float da[8], db[8];
             unpack8(xa, da, T());
             unpack8(xb, db, T());
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
             o[2][k] = e[2][k] - e[1][k];
             o[3][k] = e[1][k] - e[3][k];
         }
-        T* dst = v + (size_t)(i * 4) * vps + ((size_t)cb * m_pad + (size_t)cube * 6 * tpf + tl) * 32 + ch * 8;
+        T* dst = v + (size_t)(i * 4) * vps + ((size_t)sub * m_pad + (size_t)cube * 6 * tpf + tl) * 32 + coff + ch * 8;
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)j * vps) = pack8(o[j], T());
     }
@@ -701,25 +705,28 @@ extern "C" int cp360_wino_output(const cp360_wino_desc* d, const float* m, const
 
 // cp360_wino_output of THIS convolution fused with cp360_wino_input of the NEXT one (same faces, next c_in = this c_out, dense
 // pixels): v_next receives what cp360_wino_input would make of this convolution's output - same bits, no activation tensor.
-// CP360_ERR_UNSUPPORTED for faces above 9 x 9 (the cube's 32-channel image no longer fits the LDS budget that keeps two
-// workgroups per CU): the caller then runs the two kernels.
+// CP360_ERR_UNSUPPORTED for faces above 9 x 9 (the cube's 32-channel image would exceed 40 KB of LDS): the caller then runs the two
+// kernels.
 extern "C" int cp360_wino_output_input(const cp360_wino_desc* d, const float* m, const float* bias, void* v_next, void* stream) {
     WinoGeom g;
     int rc = wino_check(d, &g);
     if (rc) return rc;
     if (!m || !v_next) return CP360_ERR_NULL;
     const int pw = 2 * g.th + 2, P = 6 * d->face * d->face;
-    const size_t lds = (size_t)((P * 64 + 15) & ~15) + (size_t)6 * pw * pw * 2;
-    if (d->face > 9 || lds > 40 * 1024) return CP360_ERR_UNSUPPORTED;
-    const int nsub = (d->c_out + 31) / 32;
+    // 32 channels per workgroup: a cube's image must stay under 40 KB (faces up to 9 x 9).  The 16-channel form for 16 x 16 faces (49 KB,
+    // 250 workgroups for one cube, 64-byte pieces of M) was built and measured at 57 us against 18 + 18 for the two kernels: not used.
+    constexpr int cb = 32;
+    const size_t lds = (size_t)((P * cb * 2 + 15) & ~15) + (size_t)6 * pw * pw * 2;
+    if (lds > 40 * 1024) return CP360_ERR_UNSUPPORTED;
+    const int nsub = (d->c_out + 31) / 32, nblk = nsub * (32 / cb);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)((d->n_img / 6) * nsub));
+    dim3 grid((unsigned)((d->n_img / 6) * nblk));
     if (d->dtype == CP360_F16)
-        hipLaunchKernelGGL((wino_out_in_kernel<f16_raw>), grid, dim3(768), lds, st, m, bias, (f16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
-                           g.m_pad, d->relu, nsub);
+        hipLaunchKernelGGL((wino_out_in_kernel<f16_raw, 32>), grid, dim3(768), lds, st, m, bias, (f16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
+                           g.m_pad, d->relu, nsub, nblk);
     else
-        hipLaunchKernelGGL((wino_out_in_kernel<bf16_raw>), grid, dim3(768), lds, st, m, bias, (bf16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
-                           g.m_pad, d->relu, nsub);
+        hipLaunchKernelGGL((wino_out_in_kernel<bf16_raw, 32>), grid, dim3(768), lds, st, m, bias, (bf16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
+                           g.m_pad, d->relu, nsub, nblk);
     CP360_CHECK_HIP();
     return CP360_OK;
 }

@@ -213,11 +213,11 @@ def test_clstm_wino_lazy_load_through_the_c_abi():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
-@pytest.mark.parametrize('n,n_img', [(7, 24), (8, 12), (5, 6), (7, 30)])
+@pytest.mark.parametrize('n,n_img', [(7, 24), (8, 12), (5, 6), (7, 30), (9, 6)])
 def test_wino_fused_output_input_equals_the_two_kernels(n, n_img, prec):
     """cp360_wino_output_input (one launch between two convolutions of the ConvLSTM) against cp360_wino_output followed by
     cp360_wino_input: the same V, bit for bit, on every valid tile row - c_out = 264 ends inside a 32-channel block (the
-    next V's zero padding), 30 faces span two 384-row tile blocks; 16x16 faces are refused (the caller runs the two kernels)."""
+    next V's zero padding), 30 faces span two 384-row tile blocks; 9x9 is the largest face it takes."""
     dt = _TDT[prec]
     cin, cmid, cout = 40, 264, 64
     x = hashrng.normal(7900 + n, (n_img, cin, n, n))
@@ -252,6 +252,6 @@ def test_wino_fused_output_input_equals_the_two_kernels(n, n_img, prec):
 @pytest.mark.gpu
 def test_wino_fused_output_input_refuses_large_faces():
     c1 = ops.WinoConv(torch.zeros(32, 32, 3, 3), None, False, torch.float16, DEV)
-    xt = torch.zeros((6, 16, 16, 32), dtype=torch.float16, device=DEV)
+    xt = torch.zeros((6, 16, 16, 32), dtype=torch.float16, device=DEV)           # a cube's 32-channel image: 98 KB of LDS
     m, d = c1.sums(xt)
     assert c1.output_input(m, d, c1) is None
