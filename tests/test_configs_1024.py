@@ -127,9 +127,10 @@ def test_c4_shard_4_clips_x_16_frames_batched(shard, prec):
 def test_c2_variant_cube_256_pipeline(prec):
     """SURVEY 8, "C2 ... cd=256 optional variant" (the reference's only smoke test uses 256-pixel faces, model/cube_pad.py:256-261):
     a 1024x2048 clip through cube 256 -> layer4 8x8 -> ConvLSTM at 8x8 faces -> 16x32 map, against the oracle end to end.
-    None of the fused kernels is specialised to this geometry: the static stage takes the per-convolution path
-    (cp360_resnet_plan_describe says so) and the ConvLSTM the generic ring kernel (6 * 64 = 384 pixels per cube do not fit the
-    clip-resident tile)."""
+    None of the fused static-stage kernels is specialised to this geometry: the static stage takes the per-convolution path
+    (cp360_resnet_plan_describe says so).  The ConvLSTM of ONE clip at 8x8 faces runs the HALF variant of the clip-resident kernel
+    (conv_clip_kernel<T, 2>: half a cube per tile, the whole cube resident); four clips would run in the Winograd domain
+    (tests/test_wino.py::test_wino_cell_window_matches_oracle[bf16-8-4])."""
     from cp_360_weakly_supervised_saliency_amd.pipeline import SaliencyEngine
     cd, t = 256, 3
     rs = synth.resnet50_state(seed=1)
