@@ -62,6 +62,35 @@ def test_wino_planner_and_sizes():
     assert L.cp360_wino_gemm(C.byref(d), None, None, None, None) == -6
 
 
+def test_wino_entry_points_validate_without_gpu():
+    """Argument validation of every cp360_wino_* entry point happens before any launch (error codes on the CPU box)."""
+    L = _lib.lib()
+    one = C.c_void_p(16)
+    d = _lib.WinoDesc()
+    d.dtype, d.n_img, d.face, d.c_in, d.pix_stride, d.c_out, d.ld_out, d.out_coff, d.relu = _lib.BF16, 6, 7, 64, 64, 64, 0, 0, 1
+    assert L.cp360_wino_input(C.byref(d), None, one, None) == -5 and L.cp360_wino_input(C.byref(d), one, None, None) == -5
+    assert L.cp360_wino_gemm(C.byref(d), one, one, None, None) == -5
+    assert L.cp360_wino_output(C.byref(d), None, None, one, None) == -5
+    assert L.cp360_wino_output_input(C.byref(d), one, None, None, None) == -5
+    assert L.cp360_wino_pack_weights(C.byref(d), None, one, None) == -5
+    assert L.cp360_wino_output_gates(C.byref(d), one, None, one, one, one, 128, 64, None, None, None, 0, 0, None) == -5   # bias is required
+    d.c_out = 72                                                             # the gate epilogue splits c_out into 4 gates of Hc % 4 == 0
+    assert L.cp360_wino_output_gates(C.byref(d), one, one, one, one, one, 128, 64, None, None, None, 0, 0, None) == -6
+    d.c_out = 64
+    assert L.cp360_wino_output_gates(C.byref(d), one, one, one, one, one, 64, 56, None, None, None, 0, 0, None) == -1     # h_coff + Hc > ld_h
+    assert L.cp360_wino_output_gates(C.byref(d), one, one, one, one, one, 128, 64, None, one, None, 0, 0, None) == -1     # x_next without minmax
+    d.pix_stride = 32
+    assert L.cp360_wino_input(C.byref(d), one, one, None) == -1                                                            # pixel stride < c_in
+    d.pix_stride, d.ld_out = 64, 32
+    assert L.cp360_wino_output(C.byref(d), one, None, one, None) == -1                                                     # ld_out < c_out
+    d.ld_out, d.face = 0, 1
+    assert L.cp360_wino_packed_bytes(C.byref(d)) == 0                                                                      # faces of at least 2 x 2
+    d.face = 64
+    assert L.cp360_wino_input(C.byref(d), one, one, None) == -8 and L.cp360_wino_output_input(C.byref(d), one, None, one, None) == -8
+    # the cell context: queries on a context without a loaded cell, and the f32 cell
+    assert L.cp360_clstm_wino_state(None, 4, 7) == 0 and L.cp360_clstm_load_wino(None, one, one, one, None) == -5
+
+
 # ------------------------------------------------------------------ the convolution
 @pytest.mark.gpu
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
