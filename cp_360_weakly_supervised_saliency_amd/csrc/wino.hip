@@ -73,13 +73,15 @@ __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off
                      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
 }
 
-// ---- structure knobs (defaults = what tools/wino_stamps_ab.sh measured fastest; the others stay buildable for A/B)
-// WINO_LEAD_DMA 1: the four LEADING waves issue the whole fill (10 instructions each: their own 16-row slot and the slot of their
-//   SIMD partner), the lagging waves none.  The two waves of a SIMD meet at one barrier per sub-step; the one that wins the
-//   matrix-pipe arbitration (the older, leading wave) arrives ~600 cycles early and waits, the other sets the period - so the
-//   fill's issue time (~60-100 cycles per instruction) moves to the wave that has the slack.
-// WINO_DMA_PLACE 0: the refill in front of the HEAD's MFMAs, 2: spread behind the TAIL's MFMA columns, 3: behind the TAIL's last MFMA.
-// WINO_NO_B2 1: no second barrier per sub-step (it only paced the two wave groups; no LDS hazard depends on it).
+// ---- structure knobs (defaults = what tools/wino_stamps_ab.sh measured fastest, in cycles per sub-step by in-kernel stamps; the others
+// stay buildable for A/B.  docs/rounds/r05.md has the table: 2620 cycles for the first version, 2348 for the defaults)
+// WINO_NO_B2 1 (default): one barrier per sub-step - the second only paced the two wave groups, no LDS hazard depends on it (2620 -> 2476).
+// WINO_DMA_PLACE 2 (default): the refill's DMAs spread behind the TAIL's MFMA columns (-> 2388); 0: in front of the HEAD's MFMAs;
+//   3: behind the TAIL's last MFMA.
+// WINO_HEAD_PRIO 1 (default): a lagging wave raises its priority for its HEAD's MFMAs: both waves of a SIMD then reach the barrier
+//   together (-> 2348; a STATIC priority for either group only swaps who waits).
+// WINO_LEAD_DMA 0 (default); 1: the four leading waves (which win the matrix-pipe arbitration and wait ~600 cycles at the barrier)
+//   issue the whole fill, 10 DMAs each, the lagging waves none - measured SLOWER (2660): the lagging HEAD got longer.
 #ifndef WINO_LEAD_DMA
 #define WINO_LEAD_DMA 0
 #endif
