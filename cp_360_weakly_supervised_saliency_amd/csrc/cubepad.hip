@@ -24,7 +24,7 @@
 // coalesced loads too, the strips are short gathers from neighbouring faces that
 // sit in L2 because the same workgroup reads those faces as its own centres).
 // LX = lanes per output row (power of two >= Wp, capped at 64) so small faces
-// (9x9 ConvLSTM tiles) still fill a wave with several rows.
+// (9x9 ConvLSTM tiles) still fill a wave with several rows.  Rows of at most 64 elements: corner stitches by wavefront shuffle.
 template <typename T, int LOG_LX>
 __global__ __launch_bounds__(256) void cubepad_nchw_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            int C, CubePadGeom g) {
@@ -37,6 +37,35 @@ __global__ __launch_bounds__(256) void cubepad_nchw_kernel(const T* __restrict__
     const size_t in_face = (size_t)C * n * n, out_face = (size_t)C * Hp * Wp;
     const T* xin = x + (size_t)grp * 6 * in_face + (size_t)c * n * n;
     T* yout = y + (size_t)grp * 6 * out_face + (size_t)c * Hp * Wp;
+    if (Wp <= LX) {
+        // A padded row sits inside one wave (LX <= 64 consecutive lanes): the corner stitch is a WAVEFRONT SHUFFLE.  A corner of
+        // make_cubepad_edge (cube_pad.py:83-90,164-176) whose top / down pad is not deeper than its left / right pad repeats
+        // the end element of the top / down strip along the row - the element the lane at column pl (left corners) or
+        // pl + n - 1 (right corners) of the SAME row has just gathered - so the corner lanes take it from that lane instead of
+        // evaluating cubepad_src() and gathering it again.  (The other case - a deeper top / down pad - repeats a left / right
+        // strip element down a COLUMN, i.e. across rows that other waves own: those corners keep the gather.)
+        const int j = lx;
+        const bool in_l = j < g.pl, in_r = j >= g.pl + n;
+        const int src_lane = (int)(threadIdx.x & 63 & ~(LX - 1)) + (in_l ? g.pl : g.pl + n - 1);
+        for (int f = 0; f < 6; ++f) {
+            for (int i = ly; i < Hp; i += ROWS) {
+                const bool in_t = i < g.pt, in_d = i >= g.pt + n;
+                const bool stitched = (in_l | in_r) && (in_t | in_d) && (in_t ? g.pt : g.pd) <= (in_l ? g.pl : g.pr);
+                T v = 0;
+                if (j < Wp && !stitched) {
+                    const int s = cubepad_src(f, i, j, g);   // f'*n*n + i'*n + j'
+                    const int sf = s / (n * n);
+                    v = xin[(size_t)sf * in_face + (s - sf * n * n)];
+                }
+                // every lane of the row's segment executes the shuffle (rows of one segment share i, so a corner's source lane is live)
+                T sv;
+                if constexpr (sizeof(T) == 8) sv = (T)__shfl((long long)v, src_lane);
+                else sv = (T)__shfl((int)v, src_lane);
+                if (j < Wp) yout[(size_t)f * out_face + (size_t)i * Wp + j] = stitched ? sv : v;
+            }
+        }
+        return;
+    }
     for (int f = 0; f < 6; ++f) {
         for (int i = ly; i < Hp; i += ROWS) {
             for (int j = lx; j < Wp; j += LX) {

@@ -24,7 +24,14 @@ struct WinoK {
     const unsigned char* v;      // [16][nsub][m_pad][64 B]
     float* m;                    // [16][m_pad][ldm]
     int nsub, nt, mt, m_pad, ldm, c_out, reverse;
+    int tpf, th, odd;            // tiles per face, per face side; odd = the faces are odd-sized (0: every row of M is written)
 };
+
+// Odd faces (w = 2 th - 1): a tile of the last tile row / column keeps only the first row / column of its 2 x 2 outputs, and
+// A^T M A computes those without transform-domain row 3 / column 3 - 31 of a 7x7 face's 256 (tile, position) pairs are never read.
+// The GEMM does not store them and the output transforms do not load them (12 % of M's bytes in both directions).
+__device__ __forceinline__ bool wino_dead_row(int pos, int ty, int th) { return (pos >> 2) == 3 && ty == th - 1; }
+__device__ __forceinline__ bool wino_dead_col(int pos, int tx, int th) { return (pos & 3) == 3 && tx == th - 1; }
 
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4); }
 
@@ -124,10 +131,10 @@ __device__ unsigned long long g_wino_stamps[256 * 2 * 8 * 6];
 // registers).  A sub-step is a HEAD (fragment reads of its LDS stage, the first 6 columns; a column's registers are re-loaded
 // with column 6 + j as soon as its MFMAs are issued) and a TAIL (the other 6 columns, from registers); the two waves of a
 // SIMD (w and w + 4) run half a sub-step apart (waves 4-7 LAG: their TAIL of sub-step s-1 comes before their HEAD of s).
-template <typename T, bool LAG>
+template <typename T, bool LAG, int MJ_ = 12>
 __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, const int pos, const int nt_i, const int mt_i,
                                           const int wave, const int lane, const int wch0, const int wrow0) {
-    constexpr int NS = WG_NS, MJ = 12, JH = 6;
+    constexpr int NS = WG_NS, MJ = MJ_, JH = MJ_ / 2;
     constexpr bool LOADER = !WINO_LEAD_DMA || !LAG;              // this wave issues DMAs
     constexpr int NU = WINO_LEAD_DMA ? 10 : 5;                   // ... this many per sub-step
     const int nsub = p.nsub;
@@ -213,7 +220,7 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         _Pragma("unroll") for (int j = JH; j < MJ; ++j) {                                                  \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) WINO_MMA(acc[i][j], a[i], b[j - JH]);            \
             if (LOADER && REFILL && WINO_DMA_PLACE == 2)                                                   \
-                _Pragma("unroll") for (int u = (j - JH) * (NU / 5); u < (j - JH + 1) * (NU / 5) && u < NU; ++u) dma(u); \
+                _Pragma("unroll") for (int u = (j - JH) * (NU / 5); u < (j == MJ - 1 ? NU : (j - JH + 1) * (NU / 5)) && u < NU; ++u) dma(u); \
         }                                                                                                  \
         if (LOADER && REFILL && WINO_DMA_PLACE == 3)                                                       \
             _Pragma("unroll") for (int u = 0; u < NU; ++u) dma(u);                                         \
@@ -254,12 +261,21 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
     // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores).  Tile rows outermost:
     // the four 64-byte pieces of a row's 256 bytes leave back to back and merge into full lines in L2
     float* mp = p.m + ((size_t)pos * p.m_pad + (size_t)mt_i * WG_BM + wrow0 + lrow) * p.ldm + nt_i * WG_BN + wch0 + lchunk * 4;
+    const bool edge_pos = p.odd && ((pos >> 2) == 3 || (pos & 3) == 3);        // (uniform) this position has never-read tiles
+    int t0 = 0;                                                                 // this lane's tile inside its face, block 0
+    if (edge_pos) t0 = (mt_i * WG_BM + wrow0 + lrow) % p.tpf;
 #pragma unroll
-    for (int j = 0; j < MJ; ++j)
+    for (int j = 0; j < MJ; ++j) {
+        bool dead = false;
+        if (edge_pos) {
+            const int t = p.tpf == 16 ? t0 : (t0 + j * 16) % p.tpf, ty = t / p.th, tx = t - ty * p.th;
+            dead = wino_dead_row(pos, ty, p.th) || wino_dead_col(pos, tx, p.th);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out)
+            if (!dead && nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out)
                 *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
+    }
 }
 
 template <typename T>
@@ -279,6 +295,19 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_kernel(const WinoK p) {
         pos = rest / p.mt;
     }
     const int wch0 = (wave >> 1) * 64, wrow0 = (wave & 1) * 192;
+#if WINO_ABL & 8                                                    // timing ablation: positions whose last tile row / column is unused skip column blocks
+    const int cls = ((pos >> 2) == 3) + ((pos & 3) == 3);
+    if (cls == 1) {
+        if (wave < 4) gemm_body<T, false, 10>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
+        else          gemm_body<T, true, 10>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
+        return;
+    }
+    if (cls == 2) {
+        if (wave < 4) gemm_body<T, false, 8>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
+        else          gemm_body<T, true, 8>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
+        return;
+    }
+#endif
     if (wave < 4) gemm_body<T, false>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
     else          gemm_body<T, true>(p, lds, pos, nt_i, mt_i, wave, lane, wch0, wrow0);
 }
@@ -378,8 +407,11 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, 
             o[2][k] = e[2][k] - e[1][k];
             o[3][k] = e[1][k] - e[3][k];
         }
+        // (never-read positions of an odd face's last tile row / column: zeros - the GEMM's multiplies on them toggle nothing)
+        const bool dead_r = (w & 1) && i == 3 && ty == th - 1, dead_c = (w & 1) && tx == th - 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)j * pstride) = pack8(o[j], T());
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<u32x4*>(dst + (size_t)j * pstride) = (dead_r || (dead_c && j == 3)) ? u32x4{0u, 0u, 0u, 0u} : pack8(o[j], T());
     }
 }
 
@@ -389,10 +421,43 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, 
 // callers issue two or four calls before the first use: these kernels have few threads per CU and live on memory parallelism).
 // Address = (uniform plane base) + (32-bit per-thread byte offset): the "scalar base + vector offset" load form, one offset register
 // for all 16 loads instead of 16 64-bit pointers.
-__device__ __forceinline__ void load_positions(const float* __restrict__ m, size_t pstride, unsigned voff, f32x4 (&mm)[16]) {
+// dead_r / dead_c: this tile is in the last tile row / column of an odd face - the GEMM does not store transform-domain row 3 /
+// column 3 there and nothing it could hold reaches an output that is kept (they only enter the 2 x 2 outputs past the face).
+// MODE 0: all sixteen loads as they are (every row of M must then have been written); 1: the dead positions are not loaded
+// (predicated loads, zeros stand in); 2: a dead position is loaded from the SAME position of the tile one column / row back
+// (byte offsets back_c / back_r) - a live value another lane of the workgroup fetches anyway, so the sixteen loads stay
+// unconditional in the "scalar base + vector offset" form and the dead lines are still never touched.
+// Knobs (A/B by tools/wino_cell_probe.py; defaults = measured fastest per kernel):
+#ifndef WINO_DL_OUTIN
+#define WINO_DL_OUTIN 2
+#endif
+#ifndef WINO_DL_GATES
+#define WINO_DL_GATES 1
+#endif
+#ifndef WINO_DL_OUT
+#define WINO_DL_OUT 1
+#endif
+template <int MODE>
+__device__ __forceinline__ void load_positions(const float* __restrict__ m, size_t pstride, unsigned voff, f32x4 (&mm)[16],
+                                               bool dead_r, bool dead_c, unsigned back_r, unsigned back_c) {
+    auto ld = [&](int p, unsigned off) __attribute__((always_inline)) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(m + (size_t)p * pstride) + off);
+    };
+    if constexpr (MODE == 1) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
-        mm[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(m + (size_t)p * pstride) + voff);
+        for (int p = 0; p < 12; ++p)
+            if ((p & 3) != 3) mm[p] = ld(p, voff);
+        mm[3] = mm[7] = mm[11] = mm[12] = mm[13] = mm[14] = mm[15] = z;
+        if (!dead_c) { mm[3] = ld(3, voff); mm[7] = ld(7, voff); mm[11] = ld(11, voff); }
+        if (!dead_r) { mm[12] = ld(12, voff); mm[13] = ld(13, voff); mm[14] = ld(14, voff); }
+        if (!dead_r && !dead_c) mm[15] = ld(15, voff);
+    } else {
+        const unsigned vc = MODE == 2 && dead_c ? voff - back_c : voff, vr = MODE == 2 && dead_r ? voff - back_r : voff;
+        const unsigned vrc = MODE == 2 ? vc - (voff - vr) : voff;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) mm[p] = ld(p, p == 15 ? vrc : (p >= 12 ? vr : ((p & 3) == 3 ? vc : voff)));
+    }
 }
 __device__ __forceinline__ void out_transform(const f32x4 (&mm)[16], f32x4 (&y)[4]) {
     f32x4 s0[4], s1[4];
@@ -420,10 +485,11 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int tg = (int)(idx / ng), c = (int)(idx - (long long)tg * ng) * 4;
         f32x4 mm[16], y[4];
-        load_positions(m, pstride, (unsigned)((tg * ldm + c) * 4), mm);          // < 2^32: checked at launch
+        const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
+        load_positions<WINO_DL_OUT>(m, pstride, (unsigned)((tg * ldm + c) * 4), mm, (w & 1) && ty == th - 1, (w & 1) && tx == th - 1,
+                                    (unsigned)(th * ldm * 4), (unsigned)(ldm * 4));   // < 2^32: checked at launch
         const f32x4 bb = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         out_transform(mm, y);
-        const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
@@ -464,15 +530,16 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
         const int tl = it / NG, g = it - tl * NG, c = cb * CB + g * 4;
         f32x4 y[4];
         f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int f = tl / tpf, t = tl - f * tpf, ty = t / th, tx = t - ty * th;
         if (c < c_out) {
             f32x4 mm[16];
-            load_positions(m, pstride, (unsigned)(((cube * 6 * tpf + tl) * ldm + c) * 4), mm);
+            load_positions<WINO_DL_OUTIN>(m, pstride, (unsigned)(((cube * 6 * tpf + tl) * ldm + c) * 4), mm, (w & 1) && ty == th - 1,
+                                          (w & 1) && tx == th - 1, (unsigned)(th * ldm * 4), (unsigned)(ldm * 4));
             if (bias) bb = *reinterpret_cast<const f32x4*>(bias + c);
             out_transform(mm, y);
         } else {                                                           // channels past c_out: the next V's zero padding
             y[0] = y[1] = y[2] = y[3] = bb;
         }
-        const int f = tl / tpf, t = tl - f * tpf, ty = t / th, tx = t - ty * th;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
@@ -514,8 +581,10 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
             o[3][k] = e[1][k] - e[3][k];
         }
         T* dst = v + (size_t)(i * 4) * vps + ((size_t)sub * m_pad + (size_t)cube * 6 * tpf + tl) * 32 + coff + ch * 8;
+        const bool dead_r = (w & 1) && i == 3 && ty == th - 1, dead_c = (w & 1) && tx == th - 1;       // as wino_in_kernel
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(dst + (size_t)j * vps) = pack8(o[j], T());
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<u32x4*>(dst + (size_t)j * vps) = (dead_r || (dead_c && j == 3)) ? u32x4{0u, 0u, 0u, 0u} : pack8(o[j], T());
     }
 }
 
@@ -543,16 +612,17 @@ __global__ __launch_bounds__(256) void wino_gates_kernel(const float* __restrict
     const long long idx = (long long)blockIdx.x * 64 + lane;
     const bool live = idx < total;
     const int tg = live ? (int)(idx / ng) : 0, j = live ? (int)(idx - (long long)tg * ng) * 4 : 0;
+    const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
     {
         f32x4 mm[16], y[4];
-        load_positions(m, pstride, (unsigned)((tg * ldm + wv * Hc + j) * 4), mm);     // < 2^32: checked at launch
+        load_positions<WINO_DL_GATES>(m, pstride, (unsigned)((tg * ldm + wv * Hc + j) * 4), mm, (w & 1) && ty == th - 1, (w & 1) && tx == th - 1,
+                                      (unsigned)(th * ldm * 4), (unsigned)(ldm * 4));   // < 2^32: checked at launch
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + wv * Hc + j);
         out_transform(mm, y);
 #pragma unroll
         for (int q = 0; q < 4; ++q) ex[wv][q][lane] = y[q] + bb;
     }
     __syncthreads();
-    const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
     const int oy = 2 * ty + (wv >> 1), ox = 2 * tx + (wv & 1);
     if (!live || oy >= w || ox >= w) return;
     const size_t mpx = (size_t)(img * w + oy) * w + ox;
@@ -676,6 +746,7 @@ extern "C" int cp360_wino_gemm(const cp360_wino_desc* d, const void* v, const vo
     WinoK k;
     k.u = (const unsigned char*)packed; k.v = (const unsigned char*)v; k.m = m;
     k.nsub = g.nsub; k.nt = g.nt; k.mt = g.mt; k.m_pad = g.m_pad; k.ldm = g.ldm; k.c_out = d->c_out;
+    k.tpf = g.tpf; k.th = g.th; k.odd = d->face & 1;
     k.reverse = cp360_launch_reverse();
     dim3 grid((unsigned)(16 * g.nt * g.mt));
     hipStream_t st = (hipStream_t)stream;
@@ -783,6 +854,7 @@ extern "C" int cp360_wino_gemm_raw(int dtype, const void* u, const void* v, floa
     WinoK k;
     k.u = (const unsigned char*)u; k.v = (const unsigned char*)v; k.m = m;
     k.nsub = nsub; k.nt = nt; k.mt = mt; k.m_pad = mt * WG_BM; k.ldm = ldm; k.c_out = c_out;
+    k.tpf = 16; k.th = 4; k.odd = 0;
     k.reverse = cp360_launch_reverse();
     dim3 grid((unsigned)(16 * nt * mt));
     hipStream_t st = (hipStream_t)stream;

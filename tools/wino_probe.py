@@ -17,6 +17,7 @@ ap.add_argument('--mt', type=int, default=1)
 ap.add_argument('--iters', type=int, default=30)
 ap.add_argument('--no-check', action='store_true', help='timing only (ablation builds compute garbage)')
 ap.add_argument('--zeros', action='store_true', help='all-zero operands: the same cycles at the clock the chip holds without data toggling (DVFS check)')
+ap.add_argument('--zero-unneeded', action='store_true', help='zero the V rows of (position, tile) pairs whose M is never read at odd faces (7x7: last tile row / column)')
 args = ap.parse_args()
 dt = {'bf16': torch.bfloat16, 'fp16': torch.float16}[args.precision]
 L = _lib.lib()
@@ -30,6 +31,13 @@ Vl = torch.randn(16, mpad, nsub * 32, device=dev).to(dt)
 if args.zeros:
     Ul.zero_()
     Vl.zero_()
+if args.zero_unneeded:
+    t = torch.arange(mpad, device=dev)
+    for pos in range(16):
+        if pos >> 2 == 3:
+            Vl[pos, (t // 4) % 4 == 3] = 0
+        if pos & 3 == 3:
+            Vl[pos, t % 4 == 3] = 0
 U = Ul.view(16, nt, 256, nsub, 32).permute(0, 1, 3, 2, 4).contiguous()
 V = Vl.view(16, mpad, nsub, 32).permute(0, 2, 1, 3).contiguous()
 M = torch.zeros(16, mpad, args.cout, device=dev, dtype=torch.float32)
