@@ -102,6 +102,15 @@ __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off
 #ifndef WINO_NO_B2
 #define WINO_NO_B2 1
 #endif
+#ifndef WINO_SKIP_DEAD
+#define WINO_SKIP_DEAD 3    // bit 0: the GEMM does not store the never-read rows of M at odd faces; bit 1: the input transforms zero their V rows (A/B)
+#endif
+#ifndef WINO_MSTORE_NT
+#define WINO_MSTORE_NT 0    // 1: the slab stores are non-temporal (A/B)
+#endif
+#ifndef WINO_MLOAD_NT
+#define WINO_MLOAD_NT 1     // bit 0: wino_out_in's loads of M are non-temporal (measured: -1.2 us per launch), bit 1: wino_gates' (+0.9 us: off)
+#endif
 #ifndef WINO_ABL
 #define WINO_ABL 0          // timing ablations (tools/wino_variants.sh): 1 = every U block aliases the first, 2 = every V block, 4 = no MFMA
 #endif
@@ -146,11 +155,12 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
     const unsigned o0 = (unsigned)((16 * wave + (lane >> 2)) * 64 + ((((lane & 3) ^ ((0 - ((4 * wave + (lane >> 4)) & 3)) & 3))) << 4));
     const unsigned lds_wave = (unsigned)(size_t)lds + (unsigned)wave * 1024;
 
-    f32x4 acc[4][MJ];
+    constexpr int MJS = (WINO_ABL & 16) ? 12 : MJ;               // (ablation 16: the skipped column blocks are still stored)
+    f32x4 acc[4][MJS];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MJS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lrow = lane & 15, lchunk = lane >> 4;
     unsigned rdst = 0;                                            // LDS destination (this wave's slot) of the refill in progress
@@ -261,11 +271,11 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
     // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores).  Tile rows outermost:
     // the four 64-byte pieces of a row's 256 bytes leave back to back and merge into full lines in L2
     float* mp = p.m + ((size_t)pos * p.m_pad + (size_t)mt_i * WG_BM + wrow0 + lrow) * p.ldm + nt_i * WG_BN + wch0 + lchunk * 4;
-    const bool edge_pos = p.odd && ((pos >> 2) == 3 || (pos & 3) == 3);        // (uniform) this position has never-read tiles
+    const bool edge_pos = (WINO_SKIP_DEAD & 1) && p.odd && ((pos >> 2) == 3 || (pos & 3) == 3);        // (uniform) this position has never-read tiles
     int t0 = 0;                                                                 // this lane's tile inside its face, block 0
     if (edge_pos) t0 = (mt_i * WG_BM + wrow0 + lrow) % p.tpf;
 #pragma unroll
-    for (int j = 0; j < MJ; ++j) {
+    for (int j = 0; j < MJS; ++j) {
         bool dead = false;
         if (edge_pos) {
             const int t = p.tpf == 16 ? t0 : (t0 + j * 16) % p.tpf, ty = t / p.th, tx = t - ty * p.th;
@@ -273,8 +283,13 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (!dead && nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out)
+            if (!dead && nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out) {
+#if WINO_MSTORE_NT
+                __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16));
+#else
                 *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
+#endif
+            }
     }
 }
 
@@ -358,9 +373,12 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 // One workgroup = one face x 64 channels (two 64-byte sub-steps): the face's padded window of (2 th + 2)^2 pixels - CubePad(1)
 // through cubepad_src(), zeros past it where w is odd - is gathered to LDS once (128 B per pixel), then every (tile, 8-channel
 // chunk) item reads its 4 x 4 window from there and stores its 16 positions.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
-template <typename T>
-__global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, T* __restrict__ v, int w, int th, int c_in,
+// TH (here and in the output transforms): th as a compile-time constant (4: the 7x7 and 8x8 faces of the ConvLSTM at cube 224 / 256 -
+// the index arithmetic of an item becomes shifts instead of 32-bit divisions, which sat in front of every item's loads), 0: generic.
+template <typename T, int TH>
+__global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, T* __restrict__ v, int w, int th_, int c_in,
                                                       int pix_stride, int nsub, int m_pad, int ncb) {
+    const int th = TH ? TH : th_;
     extern __shared__ __attribute__((aligned(16))) unsigned char patch[];
     const int img = blockIdx.x / ncb, cb = blockIdx.x - img * ncb;
     const int pw = 2 * th + 2, wp = w + 2;
@@ -408,10 +426,14 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, 
             o[3][k] = e[1][k] - e[3][k];
         }
         // (never-read positions of an odd face's last tile row / column: zeros - the GEMM's multiplies on them toggle nothing)
-        const bool dead_r = (w & 1) && i == 3 && ty == th - 1, dead_c = (w & 1) && tx == th - 1;
+        // (as a bit mask, not a select: the four stores stay unconditional and back to back)
+        const unsigned keep_r = ((WINO_SKIP_DEAD & 2) && (w & 1) && i == 3 && ty == th - 1) ? 0u : ~0u, keep_c = ((WINO_SKIP_DEAD & 2) && (w & 1) && tx == th - 1) ? 0u : ~0u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<u32x4*>(dst + (size_t)j * pstride) = (dead_r || (dead_c && j == 3)) ? u32x4{0u, 0u, 0u, 0u} : pack8(o[j], T());
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 val = pack8(o[j], T());
+            const unsigned k = j == 3 ? (keep_r & keep_c) : keep_r;
+            *reinterpret_cast<u32x4*>(dst + (size_t)j * pstride) = u32x4{val.x & k, val.y & k, val.z & k, val.w & k};
+        }
     }
 }
 
@@ -431,17 +453,22 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, 
 #ifndef WINO_DL_OUTIN
 #define WINO_DL_OUTIN 2
 #endif
+#ifndef WINO_TAB_LATE
+#define WINO_TAB_LATE 0     // wino_out_in: 1 = the CubePad source table is built behind the first loads of M (measured: more registers, slower)
+#endif
+
 #ifndef WINO_DL_GATES
 #define WINO_DL_GATES 1
 #endif
 #ifndef WINO_DL_OUT
 #define WINO_DL_OUT 1
 #endif
-template <int MODE>
+template <int MODE, bool NT = false>
 __device__ __forceinline__ void load_positions(const float* __restrict__ m, size_t pstride, unsigned voff, f32x4 (&mm)[16],
                                                bool dead_r, bool dead_c, unsigned back_r, unsigned back_c) {
     auto ld = [&](int p, unsigned off) __attribute__((always_inline)) {
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(m + (size_t)p * pstride) + off);
+        if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(m + (size_t)p * pstride) + off));
+        else return *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(m + (size_t)p * pstride) + off);
     };
     if constexpr (MODE == 1) {
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -510,10 +537,11 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 // 49 MB of V writes overlap the 98 MB of M reads instead of following them in a second launch.
 // CB = channels per workgroup: 32 (one K sub-step of the next GEMM; faces up to 9 x 9).  (CB = 16 - half a sub-step, for 16 x 16 faces,
 // where a cube's image of 32 channels would be 98 KB of LDS - works and is slower than the two kernels: see the launcher.)
-template <typename T, int CB>
-__global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restrict__ m, const float* __restrict__ bias,
-                                                          T* __restrict__ v, int w, int th, int c_out, int ldm, int m_pad, int relu,
+template <typename T, int CB, int TH>
+__global__ __launch_bounds__(768, TH == 4 ? 6 : 5) void wino_out_in_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+                                                          T* __restrict__ v, int w, int th_, int c_out, int ldm, int m_pad, int relu,
                                                           int nsub, int nblk) {
+    const int th = TH ? TH : th_;
     constexpr int ROW = CB * 2, NG = CB / 4, NCH = CB / 8;                // bytes per pixel of the image, 4-channel groups, 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int cube = blockIdx.x / nblk, cb = blockIdx.x - cube * nblk;
@@ -521,10 +549,15 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
     unsigned char* act = sm;                                               // [P][ROW]
     unsigned short* tab = reinterpret_cast<unsigned short*>(sm + ((P * ROW + 15) & ~15));   // [6][pw][pw]: pixel of the cube, 0xffff = zero
     const CubePadGeom geom{w, 1, 1, 1, 1};
-    for (int i = threadIdx.x; i < 6 * pp; i += blockDim.x) {
-        const int f = i / pp, r = i - f * pp, py = r / pw, px = r - py * pw;
-        tab[i] = (py < wp && px < wp) ? (unsigned short)cubepad_src(f, py, px, geom) : (unsigned short)0xffff;
-    }
+    // (the source table is only read in phase 2: it is built behind the first item's loads of M, not in front of them)
+    auto build_tab = [&]() __attribute__((always_inline)) {
+        for (int i = threadIdx.x; i < 6 * pp; i += blockDim.x) {
+            const int f = i / pp, r = i - f * pp, py = r / pw, px = r - py * pw;
+            tab[i] = (py < wp && px < wp) ? (unsigned short)cubepad_src(f, py, px, geom) : (unsigned short)0xffff;
+        }
+    };
+    bool tab_done = !WINO_TAB_LATE;
+    if (!WINO_TAB_LATE) build_tab();
     const size_t pstride = (size_t)m_pad * ldm;
     for (int it = threadIdx.x; it < 6 * tpf * NG; it += blockDim.x) {
         const int tl = it / NG, g = it - tl * NG, c = cb * CB + g * 4;
@@ -533,9 +566,10 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
         const int f = tl / tpf, t = tl - f * tpf, ty = t / th, tx = t - ty * th;
         if (c < c_out) {
             f32x4 mm[16];
-            load_positions<WINO_DL_OUTIN>(m, pstride, (unsigned)(((cube * 6 * tpf + tl) * ldm + c) * 4), mm, (w & 1) && ty == th - 1,
+            load_positions<WINO_DL_OUTIN, (WINO_MLOAD_NT & 1) != 0>(m, pstride, (unsigned)(((cube * 6 * tpf + tl) * ldm + c) * 4), mm, (w & 1) && ty == th - 1,
                                           (w & 1) && tx == th - 1, (unsigned)(th * ldm * 4), (unsigned)(ldm * 4));
             if (bias) bb = *reinterpret_cast<const f32x4*>(bias + c);
+            if (!tab_done) { build_tab(); tab_done = true; }
             out_transform(mm, y);
         } else {                                                           // channels past c_out: the next V's zero padding
             y[0] = y[1] = y[2] = y[3] = bb;
@@ -549,6 +583,7 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
             store4(reinterpret_cast<T*>(act + (f * ww + oy * w + ox) * ROW) + g * 4, o);
         }
     }
+    if (!tab_done) build_tab();
     __syncthreads();
     const int per_row = 6 * tpf * NCH;
     const size_t vps = (size_t)nsub * m_pad * 32;                          // elements between two positions of V
@@ -581,10 +616,13 @@ __global__ __launch_bounds__(768) void wino_out_in_kernel(const float* __restric
             o[3][k] = e[1][k] - e[3][k];
         }
         T* dst = v + (size_t)(i * 4) * vps + ((size_t)sub * m_pad + (size_t)cube * 6 * tpf + tl) * 32 + coff + ch * 8;
-        const bool dead_r = (w & 1) && i == 3 && ty == th - 1, dead_c = (w & 1) && tx == th - 1;       // as wino_in_kernel
+        const unsigned keep_r = ((WINO_SKIP_DEAD & 2) && (w & 1) && i == 3 && ty == th - 1) ? 0u : ~0u, keep_c = ((WINO_SKIP_DEAD & 2) && (w & 1) && tx == th - 1) ? 0u : ~0u;   // as wino_in_kernel
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<u32x4*>(dst + (size_t)j * vps) = (dead_r || (dead_c && j == 3)) ? u32x4{0u, 0u, 0u, 0u} : pack8(o[j], T());
+        for (int j = 0; j < 4; ++j) {
+            const u32x4 val = pack8(o[j], T());
+            const unsigned k = j == 3 ? (keep_r & keep_c) : keep_r;
+            *reinterpret_cast<u32x4*>(dst + (size_t)j * vps) = u32x4{val.x & k, val.y & k, val.z & k, val.w & k};
+        }
     }
 }
 
@@ -596,26 +634,26 @@ __device__ __forceinline__ float wsigmoid(float x) { return 1.f / (1.f + __expf(
 // per position and wave: 16 independent loads in flight per lane - with one thread per item doing all four gates the launch
 // had 96 k threads of 64 dependent-ish loads each and ran at a third of the memory system's rate), transforms them and leaves the
 // item's four pixels in LDS; after the barrier wave q finishes pixel q of every item from the four gates.
-template <typename T>
-__global__ __launch_bounds__(256) void wino_gates_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+template <typename T, int TH>
+__global__ __launch_bounds__(256, 6) void wino_gates_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                          const float* __restrict__ c_prev, float* __restrict__ c_next,
                                                          T* __restrict__ h_out, int ld_h, int h_coff, float* __restrict__ h_f32,
-                                                         int tiles, int w, int th, int Hc, int ldm, int m_pad,
+                                                         int tiles, int w, int th_, int Hc, int ldm, int m_pad,
                                                          const float* __restrict__ x_next, const float* __restrict__ minmax,
                                                          int x_coff, size_t clip_stride) {
     __shared__ f32x4 ex[4][4][64];                                 // [gate][pixel][item]: lanes of a wave touch consecutive 16-byte slots
+    const int th = TH ? TH : th_;
     const int ng = Hc >> 2;
-    const long long total = (long long)tiles * ng;
     const size_t pstride = (size_t)m_pad * ldm;
     const int tpf = th * th, P = 6 * w * w;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned total = (unsigned)tiles * (unsigned)ng, idx = blockIdx.x * 64u + lane;       // < 2^31: checked at launch
     const bool live = idx < total;
-    const int tg = live ? (int)(idx / ng) : 0, j = live ? (int)(idx - (long long)tg * ng) * 4 : 0;
+    const int tg = live ? (int)(idx / (unsigned)ng) : 0, j = live ? (int)(idx - (unsigned)tg * ng) * 4 : 0;
     const int img = tg / tpf, t = tg - img * tpf, ty = t / th, tx = t - ty * th;
     {
         f32x4 mm[16], y[4];
-        load_positions<WINO_DL_GATES>(m, pstride, (unsigned)((tg * ldm + wv * Hc + j) * 4), mm, (w & 1) && ty == th - 1, (w & 1) && tx == th - 1,
+        load_positions<WINO_DL_GATES, (WINO_MLOAD_NT & 2) != 0>(m, pstride, (unsigned)((tg * ldm + wv * Hc + j) * 4), mm, (w & 1) && ty == th - 1, (w & 1) && tx == th - 1,
                                       (unsigned)(th * ldm * 4), (unsigned)(ldm * 4));   // < 2^32: checked at launch
         const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + wv * Hc + j);
         out_transform(mm, y);
@@ -728,12 +766,12 @@ extern "C" int cp360_wino_input(const cp360_wino_desc* d, const void* in, void* 
     if (lds > 64 * 1024) return CP360_ERR_UNSUPPORTED;                 // faces up to 42 x 42
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(d->n_img * ncb));
-    if (d->dtype == CP360_F16)
-        hipLaunchKernelGGL((wino_in_kernel<f16_raw>), grid, dim3(256), lds, st, (const f16_raw*)in, (f16_raw*)v, d->face, g.th, d->c_in,
-                           d->pix_stride, g.nsub, g.m_pad, ncb);
-    else
-        hipLaunchKernelGGL((wino_in_kernel<bf16_raw>), grid, dim3(256), lds, st, (const bf16_raw*)in, (bf16_raw*)v, d->face, g.th, d->c_in,
-                           d->pix_stride, g.nsub, g.m_pad, ncb);
+#define CP360_WIN(TT, THV)                                                                                                  \
+    hipLaunchKernelGGL((wino_in_kernel<TT, THV>), grid, dim3(256), lds, st, (const TT*)in, (TT*)v, d->face, g.th, d->c_in, \
+                       d->pix_stride, g.nsub, g.m_pad, ncb)
+    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WIN(f16_raw, 4); else CP360_WIN(f16_raw, 0); }
+    else { if (g.th == 4) CP360_WIN(bf16_raw, 4); else CP360_WIN(bf16_raw, 0); }
+#undef CP360_WIN
     CP360_CHECK_HIP();
     return CP360_OK;
 }
@@ -794,12 +832,12 @@ extern "C" int cp360_wino_output_input(const cp360_wino_desc* d, const float* m,
     const int nsub = (d->c_out + 31) / 32, nblk = nsub * (32 / cb);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)((d->n_img / 6) * nblk));
-    if (d->dtype == CP360_F16)
-        hipLaunchKernelGGL((wino_out_in_kernel<f16_raw, 32>), grid, dim3(768), lds, st, m, bias, (f16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
-                           g.m_pad, d->relu, nsub, nblk);
-    else
-        hipLaunchKernelGGL((wino_out_in_kernel<bf16_raw, 32>), grid, dim3(768), lds, st, m, bias, (bf16_raw*)v_next, d->face, g.th, d->c_out, g.ldm,
-                           g.m_pad, d->relu, nsub, nblk);
+#define CP360_WOI(TT, THV)                                                                                                      \
+    hipLaunchKernelGGL((wino_out_in_kernel<TT, 32, THV>), grid, dim3(768), lds, st, m, bias, (TT*)v_next, d->face, g.th, d->c_out, \
+                       g.ldm, g.m_pad, d->relu, nsub, nblk)
+    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WOI(f16_raw, 4); else CP360_WOI(f16_raw, 0); }
+    else { if (g.th == 4) CP360_WOI(bf16_raw, 4); else CP360_WOI(bf16_raw, 0); }
+#undef CP360_WOI
     CP360_CHECK_HIP();
     return CP360_OK;
 }
@@ -817,15 +855,15 @@ extern "C" int cp360_wino_output_gates(const cp360_wino_desc* d, const float* m,
     if (x_next && (!minmax || x_coff % 4 != 0 || clip_stride % 4 != 0 || x_coff + Hc > ld_h || (x_coff < h_coff + Hc && h_coff < x_coff + Hc)))
         return CP360_ERR_BAD_SHAPE;
     const long long total = (long long)g.tiles * (Hc / 4);
+    if (total >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     const long long blocks = (total + 63) / 64;                 // one 256-thread block per 64 items
-    if (blocks >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == CP360_F16)
-        hipLaunchKernelGGL((wino_gates_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (f16_raw*)h_out, ld_h,
-                           h_coff, h_f32, g.tiles, d->face, g.th, Hc, g.ldm, g.m_pad, x_next, minmax, x_coff, clip_stride);
-    else
-        hipLaunchKernelGGL((wino_gates_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (bf16_raw*)h_out, ld_h,
-                           h_coff, h_f32, g.tiles, d->face, g.th, Hc, g.ldm, g.m_pad, x_next, minmax, x_coff, clip_stride);
+#define CP360_WG(TT, THV)                                                                                                           \
+    hipLaunchKernelGGL((wino_gates_kernel<TT, THV>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (TT*)h_out, ld_h, \
+                       h_coff, h_f32, g.tiles, d->face, g.th, Hc, g.ldm, g.m_pad, x_next, minmax, x_coff, clip_stride)
+    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WG(f16_raw, 4); else CP360_WG(f16_raw, 0); }
+    else { if (g.th == 4) CP360_WG(bf16_raw, 4); else CP360_WG(bf16_raw, 0); }
+#undef CP360_WG
     CP360_CHECK_HIP();
     return CP360_OK;
 }
