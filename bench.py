@@ -110,6 +110,31 @@ def timed(step, warmup, steps, dev, per_rank=False):
     return ((total, mine) if per_rank else total), out
 
 
+def timed_pipelined(eng, frames, finish, warmup, steps, dev):
+    """The same contract for the engine's software-pipelined form (SaliencyEngine.stream: the static stage of batch k+1 on a
+    second HIP stream beside the ConvLSTM of batch k): W untimed batches (their own fill and drain), then exactly K batches
+    between barrier + synchronize on both sides - the pipeline starts EMPTY inside the timed region and is drained inside
+    it, so every one of the K batches does all of its work there.  ``finish(maps)`` = the all-gather of a batch's maps."""
+    out = None
+    for sal in eng.stream(frames for _ in range(warmup)):
+        out = finish(sal)
+    sync(dev)
+    cpdist.barrier()
+    sync(dev)
+    t0 = time.perf_counter()
+    n = 0
+    for sal in eng.stream(frames for _ in range(steps)):
+        out = finish(sal)
+        n += 1
+    sync(dev)
+    mine = time.perf_counter() - t0
+    cpdist.barrier()
+    sync(dev)
+    total = cpdist.max_over_ranks(time.perf_counter() - t0, dev)
+    assert n == steps
+    return (total, mine), out
+
+
 class StubEngine:
     """--stub-engine: stands in for SaliencyEngine on a box WITHOUT a GPU so that this file's own main() - launcher
     contract, sharding, the all-gather, max-over-ranks timing, the JSON line - runs under
@@ -126,6 +151,10 @@ class StubEngine:
         m = frames.reshape(B, -1).float().mean(dim=1)
         ramp = torch.arange(2 * self.w * 4 * self.w, dtype=torch.float32).reshape(1, 2 * self.w, 4 * self.w)
         return m.reshape(B, 1, 1) + ramp / ramp.numel()
+
+    def stream(self, batches):
+        for frames in batches:
+            yield self(frames)
 
     def close(self):
         pass
@@ -252,7 +281,7 @@ def static_roofline(ms_per_step, B, T, cd, precision):
 
 def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, graph=False, static_only=False,
                  frame_chunk=None, source_hw=None, want_roofline=False, static_precision=None, all_steps=False,
-                 f32_input=False, stub=False, want_split=False, want_plan=False, clock_after=False):
+                 f32_input=False, stub=False, want_split=False, want_plan=False, clock_after=False, pipelined=False):
     if stub:
         eng = StubEngine(cd, B, T)
     else:
@@ -294,11 +323,23 @@ def run_workload(dev, rank, world, H, W, cd, B, T, precision, steps, warmup, gra
         sal = eng(frames)
         return cpdist.gather_maps(sal, n_clips, rank, world)
 
-    elapsed, out = timed(step, warmup, steps, dev, per_rank=True)
+    pipelined = bool(pipelined and not graph and not static_only)
+    if pipelined:
+        elapsed, out = timed_pipelined(eng, frames, lambda sal: cpdist.gather_maps(sal, n_clips, rank, world), warmup, steps, dev)
+    else:
+        elapsed, out = timed(step, warmup, steps, dev, per_rank=True)
     elapsed, mine = elapsed
     assert (static_only or out.shape[0] == n_clips) and bool(torch.isfinite(out).all())
     res = {'value': round(world * B * T * steps / elapsed, 3), 'ms_per_step': round(1000.0 * elapsed / steps, 3),
-           'roofline': None}
+           'roofline': None, 'pipelined': pipelined}
+    if pipelined:
+        # the same K steps one batch at a time (engine(frames): nothing of batch k+1 starts before batch k's maps are out) -
+        # the form every round before this one quoted as the headline; reported beside it, never as `value`
+        out_p = out.clone()                                # (gather_maps reuses its result buffer)
+        el2, out2 = timed(step, 1, steps, dev, per_rank=True)
+        res['sequential'] = {'value': round(world * B * T * steps / el2[0], 3), 'ms_per_step': round(1000.0 * el2[0] / steps, 3),
+                             'what': 'engine(frames) batch by batch on one stream, same K steps, measured right after the timed region',
+                             'same_maps': bool(torch.equal(out_p, out2))}
     if clock_after and not stub:
         # the register-only MFMA clock probe, launched right behind the timed region's last step (the chip still warm)
         res['held_clock_ghz_after'] = _safe(lambda: ops.held_clock_ghz(dev))
@@ -440,36 +481,6 @@ def level1_bench(dev, precision='fp32', reps=5):
                     'to_equi_nn + torch.max per window; PCIe copies and NCHW<->NHWC conversions of every call included'}
 
 
-def stream_bench(dev, H, W, cd, B, T, precision, steps, warmup):
-    """The headline workload as a STREAM of batches (serving): SaliencyEngine.stream() runs the static stage of batch k+1 on a
-    second HIP stream beside the ConvLSTM of batch k.  Timed over `steps` batches INCLUDING the pipeline's fill (first static
-    stage alone) and drain (last ConvLSTM alone); same bits per batch as the headline path (tests/test_dropin_level1.py)."""
-    rs = synth.resnet50_state(seed=1)
-    cs = synth.clstm_state(seed=2)
-    eng = SaliencyEngine(rs, cs, (H, W), cd, clips=B, frames=T, precision=precision, device=dev)
-    del rs, cs
-    frames = torch.stack([torch.from_numpy(synth.clip_u8(3 + b, T, H, W)) for b in range(B)]).to(dev)
-    for _ in eng.stream(frames for _ in range(warmup + 1)):
-        pass
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 0
-    for sal in eng.stream(frames for _ in range(steps)):
-        n += 1
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert n == steps and bool(torch.isfinite(sal).all())
-    static_dtype = DTYPE[eng.static_precision]
-    eng.close()
-    del eng, frames
-    torch.cuda.empty_cache()
-    return {'name': 'C4 per-GPU shard as a stream of batches: static stage of batch k+1 beside the ConvLSTM of batch k (SaliencyEngine.stream)',
-            'value': round(B * T * steps / dt, 3), 'unit': 'frames/s', 'ms_per_step': round(1000.0 * dt / steps, 3), 'steps': steps,
-            'warmup': warmup, 'dtype': DTYPE[precision], 'static_stage_dtype': static_dtype,
-            'what': 'two HIP streams; fill and drain of the two-stage pipeline inside the timed region; maps of batch k returned while '
-                    'batch k+1 is in its static stage'}
-
-
 def sliding_bench(dev, precision='bf16', n_frames=64, seq_len=5, reps=5):
     """The reference's temporal workload as it runs it (temporal_model/test_temporal.py:57-62, config.yaml:34): a stride-1
     sliding window of seq_len 5 over ONE video's cube_feat sequence - every window is its own min / max normalisation,
@@ -600,6 +611,9 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary precisions / configs (N = 1)')
     ap.add_argument('--frame-chunk', type=int, default=0, help='frames per static-stage group (0 = all)')
     ap.add_argument('--graph', action='store_true', help='replay the step from a HIP graph (launch-bound small configs)')
+    ap.add_argument('--sequential', action='store_true',
+                    help='time engine(frames) batch by batch on one stream instead of the software-pipelined stream of batches '
+                         '(SaliencyEngine.stream); without it the sequential figure is reported beside the headline')
     ap.add_argument('--source', default='', help='decoded frame size HxW: include the PIL-exact Lanczos resize (K0) in the step')
     ap.add_argument('--all-steps', action='store_true',
                     help='return_all_steps: one map per ConvLSTM step, [clips, T, 2w, 4w] gathered instead of [clips, 2w, 4w]')
@@ -634,7 +648,8 @@ def main():
     head = run_workload(dev, rank, world, H, W, args.cube, B, T, args.precision, args.steps, args.warmup,
                         graph=args.graph, static_only=args.static_only, frame_chunk=args.frame_chunk or None,
                         source_hw=src_hw, want_roofline=(rank == 0), static_precision=args.static_precision or None,
-                        all_steps=args.all_steps, f32_input=args.f32_input, stub=args.stub_engine, want_split=(rank == 0))
+                        all_steps=args.all_steps, f32_input=args.f32_input, stub=args.stub_engine, want_split=(rank == 0),
+                        pipelined=not args.sequential)
 
     if rank == 0:
         line = {
@@ -655,9 +670,16 @@ def main():
                        'graph_replay': bool(args.graph),
                        'temporal_stage_dtype': DTYPE[args.precision], 'static_stage_dtype': head['static_dtype'],
                        'static_stage_fp16_fallback': head['fp16_fallback'],
-                       'parallelism': 'clips sharded over %d GPU(s), 1 all-gather of maps' % world},
+                       'parallelism': 'clips sharded over %d GPU(s), 1 all-gather of maps' % world,
+                       # how the K timed steps are issued: as a stream of batches through the engine's two-stage software pipeline
+                       # (static stage of batch k+1 on a second HIP stream beside the ConvLSTM of batch k; the pipeline starts empty
+                       # and is drained INSIDE the timed region; per-batch maps bit-identical to the sequential form), or one by one
+                       'pipelining': ('SaliencyEngine.stream: two HIP streams, fill + drain inside the timed region'
+                                      if head.get('pipelined') else 'none: engine(frames) batch by batch')},
             'roofline': head['roofline'],
             'cpu_baseline': None,
+            # the same K steps WITHOUT pipelining (the form rounds 1-4 quoted as `value`)
+            'sequential': head.get('sequential'),
             # diagnosis of multi-GPU runs (not part of `value`): each rank's own ms per step before the closing barrier,
             # and the single collective of the path - the all-gather of the maps - timed alone after the timed region
             'ms_per_step_per_rank': head.get('ms_per_step_per_rank'),
@@ -694,14 +716,15 @@ def main():
                                                                     None, kw.get('all_steps', False), kw.get('f32_input', False)),
                             'dtype': DTYPE[prec], 'static_stage_dtype': r['static_dtype'], 'graph_replay': bool(kw.get('graph')),
                             'value': r['value'], 'unit': 'frames/s', 'ms_per_step': r['ms_per_step'], 'steps': steps, 'warmup': warmup,
-                            'roofline': r['roofline'],
-                            **{k: r[k] for k in ('static_plan', 'convlstm_winograd', 'held_clock_ghz_after', 'timed_region_s') if k in r}}
+                            'roofline': r['roofline'], 'pipelined': bool(r.get('pipelined')),
+                            **{k: r[k] for k in ('static_plan', 'convlstm_winograd', 'held_clock_ghz_after', 'timed_region_s', 'sequential')
+                               if k in r}}
                 guarded(name, run)
 
             # the headline workload held for >= 3 s of timed region (MI355X_MICROARCH.md, DVFS give-back: a clock is believed after
             # >= 2 s of back-to-back load; the headline's own region is steps x ~13 ms)
             add('C4 per-GPU shard, SUSTAINED: the headline workload for 250 steps (>= 3 s of timed region)', 1024, 2048, 224, 4, 16,
-                args.precision, 250, 5, clock_after=True)
+                args.precision, 250, 5, clock_after=True, pipelined=not args.sequential)
             add('C4 per-GPU shard, fp32 (the 1e-3 parity precision)', 1024, 2048, 224, 4, 16, 'fp32', 3, 1)
             add('C4 per-GPU shard, bf16 in BOTH stages (static stage bf16 instead of fp16)', 1024, 2048, 224, 4, 16, 'bf16', 3, 1,
                 static_precision='bf16')
@@ -719,7 +742,6 @@ def main():
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, f32_input=True)
             add('C4 per-GPU shard, return_all_steps: a map after every ConvLSTM step ([4, 16, 14, 28])',
                 1024, 2048, 224, 4, 16, args.precision, 5, 2, all_steps=True)
-            guarded('C4 per-GPU shard as a stream of batches', lambda: stream_bench(dev, 1024, 2048, 224, 4, 16, args.precision, 10, 2))
             guarded('reference temporal workload: sliding window', lambda: sliding_bench(dev))
             guarded('Level-1 drop-in path', lambda: level1_bench(dev))
             line['secondary'] = sec

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 // One workgroup = one face x 64 channels (two 64-byte sub-steps): the face's padded window of (2 th + 2)^2 pixels - CubePad(1)
 // through cubepad_src(), zeros past it where w is odd - is gathered to LDS once (128 B per pixel), then every (tile, 8-channel
 // chunk) item reads its 4 x 4 window from there and stores its 16 positions.  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].
-// TH (here and in the output transforms): th as a compile-time constant (4: the 7x7 and 8x8 faces of the ConvLSTM at cube 224 / 256 -
+// TH (here and in the output transforms): th as a compile-time constant (4 / 8: the 7x7, 8x8 and 16x16 faces of the ConvLSTM at cube 224 / 256 / 512 -
 // the index arithmetic of an item becomes shifts instead of 32-bit divisions, which sat in front of every item's loads), 0: generic.
 template <typename T, int TH>
 __global__ __launch_bounds__(256) void wino_in_kernel(const T* __restrict__ in, T* __restrict__ v, int w, int th_, int c_in,
@@ -501,10 +501,11 @@ __device__ __forceinline__ void out_transform(const f32x4 (&mm)[16], f32x4 (&y)[
 
 // One thread per (tile, 4-channel group): 16 independent 16-byte loads, 8-byte (16-bit types) stores; 384 k threads at 4 clips of 7x7
 // faces.  (8 channels per thread - 32 loads up front, 152 registers - measured 22 us against 17 for the same bytes.)
-template <typename T>
+template <typename T, int TH>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ m, const float* __restrict__ bias,
-                                                       T* __restrict__ out, int tiles, int w, int th, int c_out, int ldm,
+                                                       T* __restrict__ out, int tiles, int w, int th_, int c_out, int ldm,
                                                        int m_pad, int ld_out, int out_coff, int relu) {
+    const int th = TH ? TH : th_;
     const int ng = c_out >> 2;
     const long long total = (long long)tiles * ng;
     const size_t pstride = (size_t)m_pad * ldm;
@@ -769,8 +770,8 @@ extern "C" int cp360_wino_input(const cp360_wino_desc* d, const void* in, void* 
 #define CP360_WIN(TT, THV)                                                                                                  \
     hipLaunchKernelGGL((wino_in_kernel<TT, THV>), grid, dim3(256), lds, st, (const TT*)in, (TT*)v, d->face, g.th, d->c_in, \
                        d->pix_stride, g.nsub, g.m_pad, ncb)
-    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WIN(f16_raw, 4); else CP360_WIN(f16_raw, 0); }
-    else { if (g.th == 4) CP360_WIN(bf16_raw, 4); else CP360_WIN(bf16_raw, 0); }
+    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WIN(f16_raw, 4); else if (g.th == 8) CP360_WIN(f16_raw, 8); else CP360_WIN(f16_raw, 0); }
+    else { if (g.th == 4) CP360_WIN(bf16_raw, 4); else if (g.th == 8) CP360_WIN(bf16_raw, 8); else CP360_WIN(bf16_raw, 0); }
 #undef CP360_WIN
     CP360_CHECK_HIP();
     return CP360_OK;
@@ -804,12 +805,14 @@ extern "C" int cp360_wino_output(const cp360_wino_desc* d, const float* m, const
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
-    if (d->dtype == CP360_F16)
-        hipLaunchKernelGGL((wino_out_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (f16_raw*)out, g.tiles, d->face, g.th,
-                           d->c_out, g.ldm, g.m_pad, ld_out, d->out_coff, d->relu);
-    else
-        hipLaunchKernelGGL((wino_out_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (bf16_raw*)out, g.tiles, d->face, g.th,
-                           d->c_out, g.ldm, g.m_pad, ld_out, d->out_coff, d->relu);
+#define CP360_WO(TT, THV)                                                                                                      \
+    hipLaunchKernelGGL((wino_out_kernel<TT, THV>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, (TT*)out, g.tiles, d->face, \
+                       g.th, d->c_out, g.ldm, g.m_pad, ld_out, d->out_coff, d->relu)
+#define CP360_WO_T(TT) { if (g.th == 4) CP360_WO(TT, 4); else if (g.th == 8) CP360_WO(TT, 8); else CP360_WO(TT, 0); }
+    if (d->dtype == CP360_F16) CP360_WO_T(f16_raw)
+    else CP360_WO_T(bf16_raw)
+#undef CP360_WO_T
+#undef CP360_WO
     CP360_CHECK_HIP();
     return CP360_OK;
 }
@@ -861,8 +864,8 @@ extern "C" int cp360_wino_output_gates(const cp360_wino_desc* d, const float* m,
 #define CP360_WG(TT, THV)                                                                                                           \
     hipLaunchKernelGGL((wino_gates_kernel<TT, THV>), dim3((unsigned)blocks), dim3(256), 0, st, m, bias, c_prev, c_next, (TT*)h_out, ld_h, \
                        h_coff, h_f32, g.tiles, d->face, g.th, Hc, g.ldm, g.m_pad, x_next, minmax, x_coff, clip_stride)
-    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WG(f16_raw, 4); else CP360_WG(f16_raw, 0); }
-    else { if (g.th == 4) CP360_WG(bf16_raw, 4); else CP360_WG(bf16_raw, 0); }
+    if (d->dtype == CP360_F16) { if (g.th == 4) CP360_WG(f16_raw, 4); else if (g.th == 8) CP360_WG(f16_raw, 8); else CP360_WG(f16_raw, 0); }
+    else { if (g.th == 4) CP360_WG(bf16_raw, 4); else if (g.th == 8) CP360_WG(bf16_raw, 8); else CP360_WG(bf16_raw, 0); }
 #undef CP360_WG
     CP360_CHECK_HIP();
     return CP360_OK;

@@ -159,3 +159,7 @@ def test_bench_py_main_under_the_launcher_with_the_stub_engine(world):
     assert out['held_clock_ghz'] is None and out['stage_ms'] is None
     for key in ('metric', 'unit', 'vs_baseline', 'dtype', 'config'):
         assert key in out
+    # the default run issues its K steps through the engine's software pipeline (stream of batches) and reports the same K steps
+    # issued one by one beside it, with the same gathered maps
+    assert out['config']['pipelining'].startswith('SaliencyEngine.stream')
+    assert out['sequential']['value'] > 0 and out['sequential']['same_maps'] is True
