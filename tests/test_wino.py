@@ -279,6 +279,59 @@ def test_wino_fused_output_input_equals_the_two_kernels(n, n_img, prec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('n,n_img', [(7, 24), (7, 30), (5, 6), (9, 6), (3, 6)])
+def test_wino_never_read_rows_of_m_reach_no_output(n, n_img):
+    """Odd faces: the GEMM does not store transform-domain row 3 / column 3 of the tiles in a face's last tile row / column
+    (csrc/wino.hip, wino_dead_row / wino_dead_col) and no output transform may read them.  The M workspace is filled with NaN
+    before the GEMM: the rows it skips keep the NaN, and every consumer of M - the plain output transform, the fused output +
+    next-input transform, the gate epilogue - must still give finite results equal to a run on a zero-filled workspace, bit for
+    bit; the GEMM must really have skipped rows (NaN left in M), and exactly the (tile, position) pairs the rule names."""
+    dt = torch.bfloat16
+    cin, cout, Hc = 40, 64, 16
+    x = hashrng.normal(8100 + n, (n_img, cin, n, n))
+    w = hashrng.normal(8101, (cout, cin, 3, 3), 0, (2.0 / (9 * cin)) ** 0.5)
+    b = hashrng.normal(8102, (cout,), 0, 0.1)
+    conv = ops.WinoConv(torch.from_numpy(w), torch.from_numpy(b), True, dt, DEV)
+    nxt = ops.WinoConv(torch.zeros(32, cout, 3, 3), None, False, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    cp = torch.rand((n_img, n, n, Hc), device=DEV)
+    bias_g = torch.from_numpy(b).to(DEV)
+
+    def run(fill):
+        v, d = conv.input(xt)
+        _, m = conv.workspace(d)
+        m.fill_(fill)
+        conv.gemm(v, d)
+        mm = m.clone()
+        out = conv.output(mm, d).clone()
+        c_next, h32 = torch.empty_like(cp), torch.empty_like(cp)
+        xh = torch.zeros((n_img, n, n, 2 * Hc), dtype=dt, device=DEV)
+        conv.gates_from(mm, d, bias_g, cp, c_next, xh, Hc, h32)
+        vn = conv.output_input(mm, conv.desc(n_img, n), nxt)
+        vn = None if vn is None else vn[0].clone()
+        return mm, out, c_next, h32, vn
+
+    m_nan, *got = run(float('nan'))
+    m_zero, *want = run(0.0)
+    th = (n + 1) // 2
+    tiles = n_img * th * th
+    m_pad = -(-tiles // 384) * 384
+    mv = m_nan[: 16 * m_pad * cout].view(16, m_pad, cout)[:, :tiles]
+    dead = torch.isnan(mv).all(dim=2).cpu().numpy()                       # [pos, tile]: the row was not stored
+    assert not torch.isnan(mv).any(dim=2).cpu().numpy()[~dead].any()      # a row is skipped whole or not at all
+    t = np.arange(tiles) % (th * th)
+    ty, tx = t // th, t % th
+    pos = np.arange(16)[:, None]
+    rule = ((pos >> 2) == 3) & (ty == th - 1)[None] | ((pos & 3) == 3) & (tx == th - 1)[None]
+    assert np.array_equal(dead, rule) and dead.sum() == n_img * (2 * 4 * th - 1)   # per face: th tiles x 4 positions, twice, minus the corner's overlap
+    for g, wnt in zip(got, want):
+        if g is None:
+            assert wnt is None
+            continue
+        assert bool(torch.isfinite(g.float()).all()) and torch.equal(g, wnt)
+
+
+@pytest.mark.gpu
 def test_wino_fused_output_input_refuses_large_faces():
     c1 = ops.WinoConv(torch.zeros(32, 32, 3, 3), None, False, torch.float16, DEV)
     xt = torch.zeros((6, 16, 16, 32), dtype=torch.float16, device=DEV)           # a cube's 32-channel image: 98 KB of LDS
