@@ -25,6 +25,7 @@ struct WinoK {
     float* m;                    // [16][m_pad][ldm]
     int nsub, nt, mt, m_pad, ldm, c_out, reverse;
     int tpf, th, odd;            // tiles per face, per face side; odd = the faces are odd-sized (0: every row of M is written)
+    int u_pin;                   // sub-steps of a workgroup's U stream loaded with the default cache policy (the rest: non-temporal)
 };
 
 // Odd faces (w = 2 th - 1): a tile of the last tile row / column keeps only the first row / column of its 2 x 2 outputs, and
@@ -70,9 +71,17 @@ template <int N> __device__ __forceinline__ void vm_wait_upto(int n) {
 #else
 #define WINO_VPOL ""
 #endif
-__device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off, unsigned dst, bool is_u) {
+// u_nt: this piece of the weight stream is non-temporal.  The GEMM loads only the first WinoK::u_pin sub-steps of every workgroup's
+// U block with the default policy: the 1.3 GB of weights a cell update streams no longer sweep the 256 MB Infinity Cache, so the
+// 86 MB of M and the 49 MB of V between the launches stay in it, and the HEAD of every workgroup's U stream - what all 256
+// workgroups ask for at once when a launch starts - is still there from the previous cell update (tools/wino_upin_probe.sh:
+// cell update 480 us with everything default, 474 all non-temporal, 454 with the first 4-8 sub-steps default, 460+ from 16 up).
+__device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off, unsigned dst, bool is_u, bool u_nt = false) {
     unsigned keep;
-    if (is_u)
+    if (is_u && u_nt)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+    else if (is_u)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" WINO_UPOL "\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
     else
@@ -164,12 +173,13 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
 
     const int lrow = lane & 15, lchunk = lane >> 4;
     unsigned rdst = 0;                                            // LDS destination (this wave's slot) of the refill in progress
+    int fills = 0;                                                // sub-steps requested so far (uniform)
     // unit u of a sub-step's fill: pass q = u % 5 (0, 1: the U block's two 128-row passes; 2, 3, 4: the V block's three), slot half
     // u / 5 (the partner's rows: + 64 rows = + 4 KiB on both sides)
     auto dma = [&](int u) __attribute__((always_inline)) {
         const int q = u % 5, half = u / 5;
         const unsigned src = o0 + (unsigned)((q < 2 ? q : q - 2) * 0x2000 + half * 0x1000);
-        fill_one(q < 2 ? ub : vb, src, rdst + (unsigned)(q * 0x2000 + half * 0x1000), q < 2);
+        fill_one(q < 2 ? ub : vb, src, rdst + (unsigned)(q * 0x2000 + half * 0x1000), q < 2, fills >= p.u_pin);
     };
     auto refill_begin = [&](int stage) __attribute__((always_inline)) {
         rdst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE);
@@ -177,6 +187,7 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
     auto refill_end = [&]() __attribute__((always_inline)) {
         if (!(WINO_ABL & 1)) ub += WG_BN * 64;
         if (!(WINO_ABL & 2)) vb += vstep;
+        ++fills;
     };
     if (LOADER) {
 #pragma unroll
@@ -714,6 +725,13 @@ int wino_check(const cp360_wino_desc* d, WinoGeom* g) {
 }
 }  // namespace
 
+// Sub-steps (64 bytes of K) at the head of every workgroup's weight stream that keep the default cache policy (see fill_one):
+// 4 x 256 workgroups x 16 KiB = 16 MB per convolution (2 - 8 measured alike, 12 and more slower).  CP360_WINO_UPIN overrides it (A/B; a value >= the K loop = all default).
+static int wino_u_pin() {
+    static const int v = []() { const char* e = getenv("CP360_WINO_UPIN"); return e ? atoi(e) : 4; }();
+    return v;
+}
+
 extern "C" size_t cp360_wino_packed_bytes(const cp360_wino_desc* d) {
     WinoGeom g;
     return wino_check(d, &g) ? 0 : (size_t)16 * g.nt * g.nsub * WG_BN * 64;
@@ -786,6 +804,7 @@ extern "C" int cp360_wino_gemm(const cp360_wino_desc* d, const void* v, const vo
     k.u = (const unsigned char*)packed; k.v = (const unsigned char*)v; k.m = m;
     k.nsub = g.nsub; k.nt = g.nt; k.mt = g.mt; k.m_pad = g.m_pad; k.ldm = g.ldm; k.c_out = d->c_out;
     k.tpf = g.tpf; k.th = g.th; k.odd = d->face & 1;
+    k.u_pin = wino_u_pin();
     k.reverse = cp360_launch_reverse();
     dim3 grid((unsigned)(16 * g.nt * g.mt));
     hipStream_t st = (hipStream_t)stream;
@@ -896,6 +915,7 @@ extern "C" int cp360_wino_gemm_raw(int dtype, const void* u, const void* v, floa
     k.u = (const unsigned char*)u; k.v = (const unsigned char*)v; k.m = m;
     k.nsub = nsub; k.nt = nt; k.mt = mt; k.m_pad = mt * WG_BM; k.ldm = ldm; k.c_out = c_out;
     k.tpf = 16; k.th = 4; k.odd = 0;
+    k.u_pin = wino_u_pin();
     k.reverse = cp360_launch_reverse();
     dim3 grid((unsigned)(16 * nt * mt));
     hipStream_t st = (hipStream_t)stream;

@@ -290,7 +290,10 @@ int cp360_lstm_gates_next(const float* gates_partial, int splits, const float* b
  * cp360_conv_forward (exact f32 MFMA, the 1e-3 parity path).
  *   in   [n_img, w, w, pix_stride] (the first c_in channels of a pixel), n_img = 6 * cubes
  *   v    workspace of cp360_wino_v_bytes: [16][ceil(c_in / 32)][m_pad][32] (m_pad = tiles rounded up to 384)
- *   m    workspace of cp360_wino_m_bytes: f32 [16][m_pad][c_out]
+ *   m    workspace of cp360_wino_m_bytes: f32 [16][m_pad][c_out].  Odd faces (w = 2 th - 1): a tile of a face's last tile row /
+ *        column keeps only the first row / column of its 2 x 2 outputs, which A^T M A computes without transform-domain row 3 /
+ *        column 3 - cp360_wino_gemm does NOT write those rows of m (31 of a 7x7 face's 256 (tile, position) pairs), no
+ *        cp360_wino_output* reads them, and cp360_wino_input / _output_input write zeros to the matching rows of v.
  *   out  [n_img, w, w, ld_out] at channel out_coff (ld_out 0 = c_out) */
 typedef struct {
     int dtype;        /* CP360_BF16 or CP360_F16                                   */
