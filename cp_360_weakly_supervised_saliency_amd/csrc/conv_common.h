@@ -21,6 +21,8 @@ struct ConvK {
     int M, c_pad, steps_per_tap, nsteps, steps_per_split, k_total, hw_out;
     int nt, mt, m_fast;
     int clip_rows, nsub, sub_per_split;   // clip-resident kernel: pixels per clip, 64-byte sub-steps in all / per split
+    int w_pin;                            // clip-resident kernel: sub-steps at the head of a workgroup's weight stream loaded with the
+                                          // default cache policy, the rest non-temporal (conv_igemm.hip, clip_body)
     int reverse;                          // 1: work items in descending order (cp360_set_launch_order)
     int epi_direct;                       // 1: direct 16-byte epilogue, 0: LDS-staged epilogue
     int slab_rows;                        // 1: split-K slabs in packed-row column order (slab_col)

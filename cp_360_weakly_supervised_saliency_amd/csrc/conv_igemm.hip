@@ -467,6 +467,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst /* wav
         : "memory");
 }
 
+// the same with the non-temporal hint: a weight stream much larger than the 256 MB Infinity Cache, past the head of a workgroup's
+// share (ConvK::w_pin) - it then no longer sweeps the cache of the split-K slabs / activations the next launches read, and the heads
+// of the streams, which every workgroup asks for at once when the launch starts, are still there from the previous step (measured on
+// the Winograd GEMM first: csrc/wino.hip fill_one, tools/wino_upin_probe.sh)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst /* wave-uniform */) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 template <typename T, int MJ>      // MJ = 16-pixel sub-tiles per wave: 4 -> 256x128 tile, 3 LDS stages; 8 -> 256x256, 2 stages
 __global__ __launch_bounds__(512, 2) void conv_igemm_dma_kernel(const ConvK p) {
     constexpr int BN = 256, BM = 32 * MJ, NSTAGE = (MJ == 4) ? 3 : 2;
@@ -1126,9 +1143,11 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     int abuf = cb0 % G::NA;                                    // NA = 2: the tile of block cb+1 lands while block cb is computed
     int next_act = cb0;                                        // next channel block to bring in
     int woff = s_begin * WSTEP;                                // DMA position inside the tile's packed weights
+    const int wnt_from = p.w_pin >= nloc ? 0x7fffffff : (s_begin + p.w_pin) * WSTEP;   // from here on the weight DMAs are non-temporal
 
     auto issue_w = [&](int q, unsigned sbase) __attribute__((always_inline)) {
-        glds16(wbase + q * wpass + woff, sbase + q * 128 * 64);
+        if (woff >= wnt_from) glds16_nt(wbase + q * wpass + woff, sbase + q * 128 * 64);      // (uniform)
+        else glds16(wbase + q * wpass + woff, sbase + q * 128 * 64);
     };
     auto issue_a = [&](int q) __attribute__((always_inline)) {   // pass q of channel block next_act
         const int e = next_act * BKS + dchunk_a * EPC;
@@ -1930,6 +1949,12 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     k.clip_rows = 6 * d->h_out * d->w_out;
     k.nsub = k.k_total / (bk / 2);
     k.sub_per_split = (k.nsub + d->splits - 1) / d->splits;
+    {   // weight streams that cannot stay in the 256 MB Infinity Cache (the ConvLSTM's 148 - 590 MB per launch): non-temporal past
+        // the first CP360_CLIP_WPIN (default 8) sub-steps of every workgroup; small filters (layer4: 4.7 MB) keep the default policy
+        static const int wpin = []() { const char* e = getenv("CP360_CLIP_WPIN"); return e ? atoi(e) : 8; }();
+        const size_t wbytes = (size_t)((d->c_out + 255) / 256) * 256 * k.k_total * (d->dtype == CP360_F32 ? 4 : 2);
+        k.w_pin = wbytes >= ((size_t)96 << 20) ? wpin : 0x7fffffff;
+    }
     // Epilogue of the ring kernels: LDS-staged full-line stores by default; the direct 16-byte-piece
     // epilogue measured the same on the big tiles (within 1 %) and is what the two-workgroups-per-CU
     // short-K kernel uses (no LDS left for a staged tile there).  CP360_EPI=1 selects it everywhere.
