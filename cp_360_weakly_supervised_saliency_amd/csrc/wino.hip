@@ -294,7 +294,7 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (!dead && nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out) {
+            if (!(WINO_ABL & 32) && !dead && nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out) {   // (ablation 32: no slab stores)
 #if WINO_MSTORE_NT
                 __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16));
 #else
