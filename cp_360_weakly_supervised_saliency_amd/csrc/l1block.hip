@@ -318,7 +318,10 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     // ---- stage 3: conv3 in 8 passes of 32 channels (+ residual | downsample) -> out, chained next conv1
     const unsigned char* W3s = lds;
     const unsigned char* W1s = lds + W3_BYTES;
-#pragma unroll 1
+    // (the first block's form - downsample MFMAs instead of residual loads - runs its eight passes unrolled: 307 -> 286 us; the
+    //  identity form measured 362 rolled / 367 unrolled and stays rolled: tools/static_ab.sh)
+    constexpr int S3_UNROLL = (DS && NV == 56) ? 8 : 1;         // (128x128 faces: the unrolled form spills in fp16)
+#pragma unroll S3_UNROLL
     for (int p = 0; p < 8; ++p) {
         u32x4 r2[4], adn[2][2];
         if (!DS && p < 6) load_res(p + 2, r2);
