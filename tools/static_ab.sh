@@ -10,7 +10,11 @@ for spec in "$@"; do
   D=/tmp/sv_$name; mkdir -p $D
   skip=""
   for f in $FILES; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $C/$f -o $D/${f%.hip}.o || exit 1
+    src=$C/$f
+    # variant "head": tools/_exp/<file>_head.hip (an older version of the source, untracked) instead of the tree's, if present
+    if [ "$name" = head ] && [ -f $R/tools/_exp/${f%.hip}_head.hip ]; then cp $R/tools/_exp/${f%.hip}_head.hip $C/_head_tmp_$f; src=$C/_head_tmp_$f; fi
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $src -o $D/${f%.hip}.o || exit 1
+    rm -f $C/_head_tmp_$f
     skip="$skip -e /${f%.hip}.o"
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so $(ls $C/*.o | grep -v $skip) $D/*.o
