@@ -148,6 +148,19 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const float* __restrict_
     }
 }
 
+// Diagnostic build only (-DL1_STAMPS, tools/l1_stamps.sh): s_memtime stamps of wave 0 of every workgroup at the phase boundaries
+// (0 start, 1 patch landed + barrier, 2 conv2 done, 3 fragments landed + barrier, 4 + p after pass p of stage 3; 12 end); the product
+// build executes no stamp.
+#ifdef L1_STAMPS
+__device__ unsigned long long g_l1_stamps[8192 * 16];
+#define L1_STAMP(k)                                                                                         \
+    { __builtin_amdgcn_sched_barrier(0);                                                                    \
+      if (wave == 0 && lane == 0 && blockIdx.x < 8192) g_l1_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+      __builtin_amdgcn_sched_barrier(0); }
+#else
+#define L1_STAMP(k)
+#endif
+
 template <typename T, bool DS, bool NEXT, int NV, int BANDV>
 __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
@@ -168,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     const int lrow = lane & 15, lchunk = lane >> 4;
     const int wrow = wave / WPR, x0 = (wave - wrow * WPR) * 64;               // this wave's output row and first column
     const size_t row_px = ((size_t)img * N + band * BAND + wrow) * N + x0;    // its first pixel
+    L1_STAMP(0)
 
     // ---- stage 1: conv2 on the resident cube-padded band (band3x3.hip), A fragments from L2 straight into
     // registers two taps ahead: no weight ring in LDS and no barrier inside the stage (l2block.hip)
@@ -205,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patch DMAs (and the first fragments)
     __syncthreads();
+    L1_STAMP(1)
 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -226,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    L1_STAMP(2)
     // every wave is done with the patch: bring conv3's (and the next conv1's) fragments in
     __syncthreads();
     {
@@ -314,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
     if (NEXT && tid < C) bias_s[CO + tid] = bias1 ? bias1[tid] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the fragment DMAs (and the first residual pieces)
     __syncthreads();
+    L1_STAMP(3)
 
     // ---- stage 3: conv3 in 8 passes of 32 channels (+ residual | downsample) -> out, chained next conv1
     const unsigned char* W3s = lds;
@@ -396,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) ad[rb][kb] = adn[rb][kb];
         }
+        L1_STAMP(4 + p)
     }
     if (NEXT) {
         T* orow = out_next + row_px * C;
@@ -418,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
             }
         }
     }
+    L1_STAMP(12)
 }
 
 // The last block of layer1 (identity residual) with the WIDE chained conv1 (256 -> 128 = layer2.0's conv1): stages 1-2
@@ -741,3 +760,9 @@ extern "C" int cp360_l1block_forward(int dtype, const void* mid, const void* w2_
     CP360_CHECK_HIP();
     return CP360_OK;
 }
+
+#ifdef L1_STAMPS
+extern "C" int cp360_l1_stamps_read(unsigned long long* host) {      // diagnostic build only
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l1_stamps), sizeof(g_l1_stamps)) == hipSuccess ? 0 : CP360_ERR_HIP;
+}
+#endif
