@@ -9,8 +9,12 @@ clips of `--frames` synthetic HxW u8 equirectangular frames, resident in HBM bef
 One step = the whole path over that batch: equi->cube (K1), CubePad + ResNet-50-cubic (K2/K3), CAM
 (K4), window normalise (K7), T ConvLSTM steps (K5), cube->equi + channel max (K6), and for N > 1 one
 RCCL all-gather of the saliency maps.  Metric: frames/s = N * clips * frames * K / max-over-ranks
-wall time.  The timed region carries NO instrumentation; the per-kernel roofline of the dominant
-kernel (the ConvLSTM implicit-GEMM convolution) is measured with HIP events in a separate short pass
+wall time.  The K steps are issued as a stream of batches through the engine's two-stage software pipeline
+(SaliencyEngine.stream: the static stage of batch k+1 on a second HIP stream beside the ConvLSTM of batch k; the
+pipeline starts empty and is drained INSIDE the timed region; every batch's maps are the bits the one-by-one form
+gives); the same K steps issued one by one are timed right after and reported as `sequential` (--sequential makes
+them the headline).  The timed region carries NO instrumentation; the per-kernel roofline of the dominant
+kernel (the ConvLSTM convolution: its Winograd-domain GEMM) is measured with HIP events in a separate short pass
 after it.  Rank 0 prints ONE JSON line (contract in the task statement) with `roofline`,
 `cpu_baseline` (the oracle on the host cores, bounded sample, N = 1 only) and `secondary`: the other
 precisions / BASELINE configs timed by the same invocation (N = 1 only; --no-secondary skips them).
