@@ -92,8 +92,9 @@ __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off
 // ---- structure knobs (defaults = what tools/wino_stamps_ab.sh measured fastest, in cycles per sub-step by in-kernel stamps; the others
 // stay buildable for A/B.  docs/rounds/r05.md has the table: 2620 cycles for the first version, 2348 for the defaults)
 // WINO_NO_B2 1 (default): one barrier per sub-step - the second only paced the two wave groups, no LDS hazard depends on it (2620 -> 2476).
-// WINO_DMA_PLACE 2 (default): the refill's DMAs spread behind the TAIL's MFMA columns (-> 2388); 0: in front of the HEAD's MFMAs;
-//   3: behind the TAIL's last MFMA.
+// WINO_DMA_PLACE 0 (default since the weight stream became non-temporal): the refill's DMAs in front of the HEAD's MFMAs; 2: spread
+//   behind the TAIL's MFMA columns (the default while the stream swept the Infinity Cache: 2476 -> 2388 cycles then; now 469 against 461 us
+//   per cell update, five alternations on one box); 3: behind the TAIL's last MFMA (499 us).
 // WINO_HEAD_PRIO 1 (default): a lagging wave raises its priority for its HEAD's MFMAs: both waves of a SIMD then reach the barrier
 //   together (-> 2348; a STATIC priority for either group only swaps who waits).
 // WINO_LEAD_DMA 0 (default); 1: the four leading waves (which win the matrix-pipe arbitration and wait ~600 cycles at the barrier)
@@ -102,7 +103,7 @@ __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off
 #define WINO_LEAD_DMA 0
 #endif
 #ifndef WINO_DMA_PLACE
-#define WINO_DMA_PLACE 2
+#define WINO_DMA_PLACE 0
 #endif
 // WINO_HEAD_PRIO p > 0: a LAGGING wave raises its priority to p for the MFMAs of its HEAD (A/B)
 #ifndef WINO_HEAD_PRIO

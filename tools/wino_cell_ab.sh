@@ -13,7 +13,7 @@ for spec in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so $(ls $C/*.o | grep -v wino.o) $D/wino.o
 done
 cd /tmp && export TMPDIR=/tmp
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
 for spec in "$@"; do
   name=${spec%%:*}
   export CP360_LIB=/tmp/wc_$name/libcp360.so
