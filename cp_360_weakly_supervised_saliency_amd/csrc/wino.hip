@@ -116,7 +116,7 @@ __device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off
 #define WINO_SKIP_DEAD 3    // bit 0: the GEMM does not store the never-read rows of M at odd faces; bit 1: the input transforms zero their V rows (A/B)
 #endif
 #ifndef WINO_MSTORE_NT
-#define WINO_MSTORE_NT 0    // 1: the slab stores are non-temporal (A/B)
+#define WINO_MSTORE_NT 0    // cache policy of the slab stores (A/B): 1 nt (+25 us per cell update: M must stay in the Infinity Cache), 2 sc1, 3 sc0 sc1
 #endif
 #ifndef WINO_MLOAD_NT
 #define WINO_MLOAD_NT 1     // bit 0: wino_out_in's loads of M are non-temporal (measured: -1.2 us per launch), bit 1: wino_gates' (+0.9 us: off)
@@ -296,8 +296,12 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (!(WINO_ABL & 32) && !dead && nt_i * WG_BN + wch0 + i * 16 + lchunk * 4 < p.c_out) {   // (ablation 32: no slab stores)
-#if WINO_MSTORE_NT
+#if WINO_MSTORE_NT == 1
                 __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16));
+#elif WINO_MSTORE_NT == 2
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(mp + (size_t)j * 16 * p.ldm + i * 16), "v"(acc[i][j]) : "memory");
+#elif WINO_MSTORE_NT == 3
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(mp + (size_t)j * 16 * p.ldm + i * 16), "v"(acc[i][j]) : "memory");
 #else
                 *reinterpret_cast<f32x4*>(mp + (size_t)j * 16 * p.ldm + i * 16) = acc[i][j];
 #endif
