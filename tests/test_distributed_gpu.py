@@ -35,3 +35,23 @@ def test_rccl_single_rank_through_torchrun():
     d = json.loads(line)
     assert d['backend'] == 'nccl' and d['device'].startswith('cuda')
     assert d['gathered_equal_single_process'] and d['n_gpus'] == 1 and d['max_elapsed'] == 0.5
+
+
+def test_bench_py_pipelined_steps_through_torchrun_on_rccl():
+    """bench.py ITSELF with the real engine under the launcher, one rank on RCCL (CP360_DIST_FORCE_PG=1): the default, pipelined
+    form of the timed steps (SaliencyEngine.stream, two HIP streams) with the all-gather of every batch's maps inside the loop,
+    then the same steps one by one - same gathered maps, every key of the line present.  Small geometry (256x512, cube 64)."""
+    env = dict(os.environ, CP360_DIST_FORCE_PG='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--clips', '2', '--frames', '3',
+           '--equi', '256x512', '--cube', '64', '--no-secondary', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['value'] > 0
+    assert d['config']['pipelining'].startswith('SaliencyEngine.stream')
+    assert d['sequential']['same_maps'] is True and d['sequential']['value'] > 0
+    assert d['map_shape'] == [2, 4, 8] and d['allgather_bytes_per_rank'] == 2 * 4 * 8 * 4
