@@ -1357,6 +1357,73 @@ __device__ __forceinline__ void clip_body(const ConvK& p, unsigned char* lds, co
     }
 }
 
+// ------------------------------------------------------------------ pointwise 64 -> 64 (16-bit): layer1.0's conv1
+// A 1x1 convolution of 64 channels into 64 is a stream: 128 bytes in and 128 out per pixel for 8 KFLOP.  The generic 64x256-tile
+// kernel above stages it through LDS at 256 registers (two workgroups per CU): 91 us for the 1.2 M pixels of 64 frames = 3.4 TB/s.
+// Here the whole filter (8 MFMA A fragments = 32 registers) stays in a wave's registers, a wave takes blocks of 16 pixels in a
+// grid-stride loop - B fragments straight from global memory (a block's 2 KiB are contiguous), 8 MFMAs, bias + ReLU + one rounding,
+// 16-byte stores - PWU blocks at a time so that 4 KiB of loads are in flight per wave at ~100 registers (4-5 waves per SIMD).
+// Same products and the same order of the two K = 32 halves as conv_igemm_kernel: the same bits.  The traversal honours the launch
+// order (ascending / descending pixel blocks over time): the next launch starts where this one's freshest lines are.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pw64_kernel(const ConvK p) {
+    constexpr int PWU = 2;
+    const int lane = threadIdx.x & 63, lrow = lane & 15, lchunk = lane >> 4;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const T* w = reinterpret_cast<const T*>(p.w);
+    const T* in = reinterpret_cast<const T*>(p.in);
+    T* out = reinterpret_cast<T*>(p.out);
+    u32x4 a[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            a[i][kk] = *reinterpret_cast<const u32x4*>(w + (size_t)(i * 16 + lrow) * p.k_total + kk * 32 + lchunk * 8);
+    float bb[2][8];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bb[pr][e] = p.bias ? p.bias[pr * 32 + lchunk * 8 + e] : 0.f;
+    const int nblk = (p.M + 15) / 16;
+    for (int pb0 = wave_g * PWU; pb0 < nblk; pb0 += nwaves * PWU) {
+        u32x4 b[PWU][2];
+#pragma unroll
+        for (int u = 0; u < PWU; ++u) {
+            const int pb = p.reverse ? nblk - 1 - (pb0 + u) : pb0 + u;  // (descending traversal under cp360_set_launch_order)
+            const int m = min(max(pb, 0) * 16 + lrow, p.M - 1);         // (blocks past the end re-read a valid pixel; not stored)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                b[u][kk] = *reinterpret_cast<const u32x4*>(in + (size_t)m * p.pix_stride + kk * 32 + lchunk * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PWU; ++u) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i], a[i][kk], b[u][kk]);
+            const int pb = p.reverse ? nblk - 1 - (pb0 + u) : pb0 + u;
+            const int m = pb < 0 ? p.M : pb * 16 + lrow;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * pr][e] + bb[pr][e];
+                    v[4 + e] = acc[2 * pr + 1][e] + bb[pr][4 + e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (m < p.M) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ld_out + p.out_coff + pr * 32 + lchunk * 8) = pack8(v, T());
+            }
+        }
+    }
+}
+
 constexpr int CLIP_JH = 0;
 template <typename T, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_clip_kernel(const ConvK p) {
@@ -1989,6 +2056,18 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     tile_of(d, &bn_, &bm_, &slots_);
     if (bm_ == 64) {                                           // small-M launches: 64 x 64 tiles (conv_small.hip)
         cp360_launch_conv_small(k, d->dtype, st);
+        CP360_CHECK_HIP();
+        return CP360_OK;
+    }
+    // pointwise 64 -> 64 in a 16-bit type (layer1.0's conv1): the streaming kernel; CP360_PW64=0 keeps the generic tile kernel (A/B)
+    static const int use_pw64 = []() { const char* e = getenv("CP360_PW64"); return e ? atoi(e) : 1; }();
+    if (use_pw64 && d->dtype != CP360_F32 && d->kh == 1 && d->kw == 1 && d->sy == 1 && d->sx == 1 && d->pad == 0 && d->c_in == 64 &&
+        d->c_out == 64 && d->c_in2 == 0 && d->splits <= 1 && !residual && d->tile_px == 0 && d->pix_stride % 8 == 0 &&
+        d->ld_out % 8 == 0 && d->out_coff % 8 == 0 && k.M >= 4096) {
+        long long blocks = ((long long)(k.M + 15) / 16 + 7) / 8;                 // two passes of PWU blocks per wave at most ...
+        if (blocks > 256 * 8) blocks = 256 * 8;                                    // ... and a persistent grid beyond 8 workgroups per CU
+        if (d->dtype == CP360_F16) hipLaunchKernelGGL((conv_pw64_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((conv_pw64_kernel<bf16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, k);
         CP360_CHECK_HIP();
         return CP360_OK;
     }
