@@ -390,6 +390,47 @@ def test_conv_small_tile_is_what_one_frame_fp32_runs():
     assert torch.equal(auto, forced)
 
 
+def _pw64_case(prec, n_img, n, order):
+    """One 1x1, 64 -> 64 convolution + bn + relu on seeded operands (shared by the test below and its CP360_PW64=0 child)."""
+    dt = _TDT[prec]
+    w = hashrng.normal(9801, (64, 64, 1, 1), 0, (2.0 / 64) ** 0.5)
+    scale = hashrng.normal(9802, (64,), 1.0, 0.1)
+    bias = hashrng.normal(9803, (64,), 0, 0.2)
+    conv = ops.Conv(torch.from_numpy(w), torch.from_numpy(scale), torch.from_numpy(bias), 1, 0, True, dt, DEV)
+    xt = torch.from_numpy(hashrng.normal(9800 + n, (n_img, n, n, 64))).to(DEV).to(dt)
+    with ops.launch_order(order):
+        got = conv(xt)
+    wr = (torch.from_numpy(w[:, :, 0, 0]) * torch.from_numpy(scale)[:, None]).to(dt).float()
+    want = torch.relu(xt.float().cpu() @ wr.t() + torch.from_numpy(bias).float())
+    return got.cpu(), want
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n_img,n', [(24, 56), (6, 27)])
+def test_pointwise_64_to_64_streaming_kernel(prec, n_img, n, tmp_path):
+    """csrc/conv_igemm.hip conv_pw64_kernel (layer1.0's conv1, model/resnet_cubic.py:88-90: 1x1, 64 -> 64, + bn1 + relu): the
+    filter in a wave's registers, 16-pixel blocks streamed from global memory.  Against torch-CPU on identically rounded
+    operands in both traversal orders, and bit for bit against the generic 64 x 256-tile kernel on the same launch (a child
+    process with CP360_PW64=0: the switch is read once per process); 6 x 27 x 27 pixels: a ragged last block."""
+    import subprocess
+    import sys
+    outs = []
+    for order in (0, 1):
+        got, want = _pw64_case(prec, n_img, n, order)
+        assert rel_err(got.float().numpy(), want.numpy()) <= _TOL[prec]
+        outs.append(got)
+    assert torch.equal(outs[0], outs[1])                          # the traversal order never changes a result
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = str(tmp_path / 'generic.pt')
+    code = ("import torch; from tests import test_gpu_parity as t; "
+            "torch.save(t._pw64_case(%r, %d, %d, 0)[0], %r)" % (prec, n_img, n, f))
+    e = dict(os.environ, CP360_PW64='0')
+    e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert torch.equal(outs[0], torch.load(f))
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('geom', [(64, 64, 256, 14, 1, 0), (96, 200, 264, 14, 2, 0), (128, 256, 512, 10, 2, 304),
                                   (512, 1024, 2048, 7, 1, 256), (64, 64, 256, 9, 1, 3), (96, 200, 264, 14, 2, 6464),
