@@ -2063,7 +2063,7 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
     static const int use_pw64 = []() { const char* e = getenv("CP360_PW64"); return e ? atoi(e) : 1; }();
     if (use_pw64 && d->dtype != CP360_F32 && d->kh == 1 && d->kw == 1 && d->sy == 1 && d->sx == 1 && d->pad == 0 && d->c_in == 64 &&
         d->c_out == 64 && d->c_in2 == 0 && d->splits <= 1 && !residual && d->tile_px == 0 && d->pix_stride % 8 == 0 &&
-        d->ld_out % 8 == 0 && d->out_coff % 8 == 0 && k.M >= 4096) {
+        d->ld_out % 8 == 0 && d->out_coff % 8 == 0 && k.M >= 4096 && k.out != nullptr && k.partial == nullptr) {
         long long blocks = ((long long)(k.M + 15) / 16 + 7) / 8;                 // two passes of PWU blocks per wave at most ...
         if (blocks > 256 * 8) blocks = 256 * 8;                                    // ... and a persistent grid beyond 8 workgroups per CU
         if (d->dtype == CP360_F16) hipLaunchKernelGGL((conv_pw64_kernel<f16_raw>), dim3((unsigned)blocks), dim3(256), 0, st, k);

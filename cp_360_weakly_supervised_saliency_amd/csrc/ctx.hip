@@ -11,6 +11,7 @@
 // Host-side C++ only: every launch goes through the per-kernel entry points of this library, in exactly the order and
 // with exactly the descriptors the Python planning produces, so both paths give the same bits (tests/test_ctx.py).
 #include "common.h"
+#include <algorithm>
 #include <new>
 #include <stdio.h>
 #include <stdlib.h>
@@ -263,6 +264,9 @@ bool wino_wanted(const CClstm& Cl, int n_clips, int face) {
     if (Cl.dtype == CP360_F32) return false;
     cp360_wino_desc d1, d2, dg;
     wino_descs(Cl, 6 * n_clips, face, &d1, &d2, &dg);
+    // every one of the three convolutions has to be a shape the Winograd kernels take (Conv1's K = input + hidden channels is
+    // not Conv2's): a cell whose Conv1 fails the check stays on the direct kernels instead of failing in cp360_clstm_step
+    if (!cp360_wino_v_bytes(&d1) || !cp360_wino_v_bytes(&d2) || !cp360_wino_v_bytes(&dg)) return false;
     return cp360_wino_preferred(&d2) == 1;
 }
 
@@ -829,8 +833,10 @@ int clstm_run(cp360_ctx* ctx, bool dry, void* xh, const float* c_prev, float* c_
         // transform (+ bias + ReLU); the Gates convolution's output transform is the gate kernel
         cp360_wino_desc d1, d2, dg;
         wino_descs(Cl, n6, face, &d1, &d2, &dg);
-        w.wv = align_up(cp360_wino_v_bytes(&d2));
-        w.wm = align_up(cp360_wino_m_bytes(&d2));
+        // V / M are shared by the three convolutions: sized for the largest (Conv1's K = input + hidden channels exceeds Conv2's
+        // 4 * hidden when input > 3 * hidden)
+        w.wv = align_up(std::max(cp360_wino_v_bytes(&d1), std::max(cp360_wino_v_bytes(&d2), cp360_wino_v_bytes(&dg))));
+        w.wm = align_up(std::max(cp360_wino_m_bytes(&d1), std::max(cp360_wino_m_bytes(&d2), cp360_wino_m_bytes(&dg))));
         if (dry) {
             if (need) *need = w;
             return CP360_OK;

@@ -55,27 +55,30 @@ def _into_tensor_ok():
     return hasattr(dist, 'all_gather_into_tensor') and dist.get_backend() != 'gloo'
 
 
-def gather_maps(local_maps, n_clips, rank, world):
+def gather_maps(local_maps, n_clips, rank, world, reuse=False):
     """local_maps: [len(shard_clips(...)), h, w] f32 on this rank's device - or [.., T, h, w] with the per-step
     maps of ``return_all_steps`` (any trailing shape).  Returns [n_clips, ...] on every rank, ordered by clip id
     (one all_gather: 6 KB per rank at BASELINE config C4, 100 KB with all 16 per-step maps).
 
-    Nothing is allocated after the first call of a shape: an even split gathers straight into the (reused) result tensor,
-    a ragged one goes through a reused padded send / recv pair.  The result is overwritten by the next call with the same
-    shape - clone it to keep it."""
+    Default: the result is a fresh tensor the caller owns.  ``reuse=True`` (bench.py's timed loop) allocates nothing after the
+    first call of a shape: an even split gathers straight into a cached result tensor, a ragged one goes through a cached
+    padded send / recv pair - the result is then OVERWRITTEN by the next ``reuse=True`` call with the same shape (clone it to
+    keep it; a consumer on another stream must have finished reading it).  ``release_gather_buffers()`` drops the cache."""
     if world == 1 and not dist.is_initialized():
         return local_maps
     base, extra = divmod(n_clips, world)
     cap = base + (1 if extra else 0)
     tail = tuple(local_maps.shape[1:])
     key = (tail, local_maps.dtype, local_maps.device, n_clips, world)
-    bufs = _GATHER_BUFS.get(key)
+    bufs = _GATHER_BUFS.get(key) if reuse else None
     if bufs is None:
         mk = lambda *shape: torch.empty(shape + tail, dtype=local_maps.dtype, device=local_maps.device)
-        bufs = _GATHER_BUFS[key] = {'out': mk(n_clips)}
+        bufs = {'out': mk(n_clips)}
         if extra:
             bufs['send'] = torch.zeros((cap,) + tail, dtype=local_maps.dtype, device=local_maps.device)
             bufs['recv'] = mk(world, cap)
+        if reuse:
+            _GATHER_BUFS[key] = bufs
     out = bufs['out']
     if not extra:                                    # even split: rank r's block IS rows [r * base, (r + 1) * base) of the result
         send = local_maps if local_maps.is_contiguous() else local_maps.contiguous()
@@ -96,6 +99,11 @@ def gather_maps(local_maps, n_clips, rank, world):
         out[lo: lo + n].copy_(recv[r, :n])
         lo += n
     return out
+
+
+def release_gather_buffers():
+    """Drop the buffers cached by ``gather_maps(..., reuse=True)`` (call before destroy_process_group)."""
+    _GATHER_BUFS.clear()
 
 
 def max_over_ranks(value, device):

@@ -748,8 +748,8 @@ class WinoConv:
     form of the ConvLSTM convolutions (model/clstm.py:56-64) when the launch has enough tiles to fill 384-row GEMM tiles.
     weight f32 [c_out, c_in, 3, 3], bias f32 [c_out] or None.  ``preferred(n_img, face)`` = the library's planner."""
 
-    # one V / M workspace pair per (device, dtype), shared by every convolution of the cell: V is dead once the GEMM has
-    # run and M once its output transform has (stream order)
+    # one V / M workspace pair per (device, dtype, HIP stream), shared by every convolution launched on that stream: V is dead
+    # once the GEMM has run and M once its output transform has (stream order - which only holds within ONE stream, hence the key)
     _ws = {}
 
     def __init__(self, weight, bias=None, relu=False, dtype=torch.bfloat16, device='cuda'):
@@ -787,7 +787,7 @@ class WinoConv:
         return self._packed
 
     def workspace(self, d):
-        key = (self.device, self.dtype)
+        key = (self.device, self.dtype, int(torch.cuda.current_stream(self.device).cuda_stream))
         need_v, need_m = lib().cp360_wino_v_bytes(C.byref(d)), lib().cp360_wino_m_bytes(C.byref(d))
         v, m = WinoConv._ws.get(key, (None, None))
         if v is None or v.numel() < need_v:

@@ -44,12 +44,21 @@ def _worker(rank, world, port, n_clips, q, all_steps=False):
     empty = (0, 3, 14, 28) if all_steps else (0, 14, 28)
     local = torch.from_numpy(np.stack([fake(c) for c in mine])) if mine else torch.zeros(empty)
     d.barrier()
-    allmaps = d.gather_maps(local, n_clips, r, w)
+    # default: the caller owns the result (a later gather never overwrites it, nothing is cached)
+    owned = d.gather_maps(local, n_clips, r, w)
+    other = d.gather_maps(local + 2.0, n_clips, r, w)
+    assert owned.data_ptr() != other.data_ptr() and len(d._GATHER_BUFS) == 0
+    assert np.array_equal(other.numpy(), owned.numpy() + 2.0)
+    allmaps = d.gather_maps(local, n_clips, r, w, reuse=True)
     first, ptr1 = allmaps.numpy().copy(), allmaps.data_ptr()
-    # a second step with other maps: nothing new is allocated (the same send / recv / result buffers) and the result is right
-    again = d.gather_maps(local + 1.0, n_clips, r, w)
-    assert again.data_ptr() == ptr1 and len(d._GATHER_BUFS) == 1, "gather_maps allocated on its second call"
+    assert np.array_equal(first, owned.numpy())
+    # reuse=True (bench.py's timed loop), a second step with other maps: nothing new is allocated (the same send / recv / result
+    # buffers) and the result is right
+    again = d.gather_maps(local + 1.0, n_clips, r, w, reuse=True)
+    assert again.data_ptr() == ptr1 and len(d._GATHER_BUFS) == 1, "gather_maps(reuse=True) allocated on its second call"
     assert np.array_equal(again.numpy(), first + 1.0)
+    d.release_gather_buffers()
+    assert len(d._GATHER_BUFS) == 0
     t = d.max_over_ranks(1.0 + r, 'cpu')
     q.put((rank, mine, first, t))
     torch.distributed.destroy_process_group()

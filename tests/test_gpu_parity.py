@@ -431,6 +431,24 @@ def test_pointwise_64_to_64_streaming_kernel(prec, n_img, n, tmp_path):
     assert torch.equal(outs[0], torch.load(f))
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+def test_pointwise_64_to_64_raw_f32_sums_stay_on_the_generic_kernel(prec):
+    """cp360_conv_forward2 with out == NULL, partial != NULL, splits == 1 (raw f32 sums) on the shape the streaming 64 -> 64
+    kernel takes (M >= 4096): that kernel only stores packed 16-bit results, so the dispatch must leave this mode to the generic
+    kernel (round-5 advisor finding: it used to store through a null `out`).  Against torch-CPU on the rounded operands."""
+    dt = _TDT[prec]
+    n_img, n = 6, 28                                                   # M = 4704 pixels
+    w = hashrng.normal(9811, (64, 64, 1, 1), 0, (2.0 / 64) ** 0.5)
+    conv = ops.Conv(torch.from_numpy(w), None, torch.zeros(64), 1, 0, False, dt, DEV)
+    xt = torch.from_numpy(hashrng.normal(9812, (n_img, n, n, 64))).to(DEV).to(dt)
+    part, ns = conv(xt, raw_f32=True, splits=1)
+    torch.cuda.synchronize()
+    assert ns == 1
+    got = part[:n_img * n * n * 64].view(n_img * n * n, 64).cpu()
+    want = xt.float().cpu().view(-1, 64) @ torch.from_numpy(w[:, :, 0, 0]).to(dt).float().t()
+    assert rel_err(got.numpy(), want.numpy()) <= 1e-4
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('geom', [(64, 64, 256, 14, 1, 0), (96, 200, 264, 14, 2, 0), (128, 256, 512, 10, 2, 304),
                                   (512, 1024, 2048, 7, 1, 256), (64, 64, 256, 9, 1, 3), (96, 200, 264, 14, 2, 6464),

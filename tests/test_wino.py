@@ -241,6 +241,60 @@ def test_clstm_wino_lazy_load_through_the_c_abi():
 
 
 @pytest.mark.gpu
+def test_clstm_wino_step_with_input_wider_than_three_hidden():
+    """cp360_clstm_step in the Winograd domain when Conv1's K (input + hidden = 1280) exceeds Conv2's (4 * hidden = 1024): the
+    shared V workspace has to hold Conv1's transformed input (round-5 advisor finding: it was sized from Conv2 alone, so Conv1's V
+    ran into M).  The Winograd step against the direct step of the same context, and the reported workspace is large enough for
+    Conv1's V + M.  A cell whose Conv1 is not a Winograd shape (input + hidden not a multiple of 8) reports state 0."""
+    L = _lib.lib()
+    dt, code = torch.bfloat16, _lib.BF16
+    Cin, Hc = 1024, 256
+    B, w = 4, 7
+    n6, c4, cx = 6 * B, 4 * Hc, Cin + Hc
+    g = lambda seed, shape, std: torch.from_numpy(hashrng.normal(seed, shape, 0, std)).to(DEV)
+    w1, w2, wg = g(7821, (c4, cx, 3, 3), (2.0 / (9 * c4)) ** 0.5), g(7822, (c4, c4, 3, 3), (2.0 / (9 * c4)) ** 0.5), \
+        g(7823, (c4, c4, 3, 3), (2.0 / (9 * c4)) ** 0.5)
+    b1, b2, bg = g(7824, (c4,), 0.05), g(7825, (c4,), 0.05), g(7826, (c4,), 0.05)
+    h = C.c_void_p()
+    _lib.check(L.cp360_create(torch.cuda.current_device(), C.byref(h)))
+    try:
+        p = _lib.ptr
+        _lib.check(L.cp360_clstm_load(h, code, p(w1), p(b1), p(w2), p(b2), p(wg), p(bg), Cin, Hc, w, _lib.stream()))
+        assert L.cp360_clstm_wino_state(h, B, w) == 2
+        outs = []
+        for phase in range(2):
+            if phase == 1:
+                _lib.check(L.cp360_clstm_load_wino(h, p(w1), p(w2), p(wg), _lib.stream()))
+                assert L.cp360_clstm_wino_state(h, B, w) == 1
+            nb = L.cp360_clstm_workspace_bytes(h, B, w)
+            if phase == 1:
+                d1 = _lib.WinoDesc(code, n6, w, cx, cx, c4, c4, 0, 1)
+                assert nb >= L.cp360_wino_v_bytes(C.byref(d1)) + L.cp360_wino_m_bytes(C.byref(d1))
+            ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            xh = torch.from_numpy(hashrng.uniform(7830, (n6, w, w, cx), 0.0, 1.0)).to(DEV).to(dt)
+            c0 = torch.from_numpy(hashrng.uniform(7831, (n6, w, w, Hc), 0.0, 1.0)).to(DEV)
+            c1, hf = torch.empty_like(c0), torch.empty_like(c0)
+            _lib.check(L.cp360_clstm_step(h, p(xh), p(c0), p(c1), p(hf), B, w, None, None, 0, p(ws), nb, _lib.stream()))
+            torch.cuda.synchronize()
+            outs.append((c1.cpu().numpy(), hf.cpu().numpy()))
+        for a, b in zip(outs[0], outs[1]):
+            assert np.all(np.isfinite(a)) and np.max(np.abs(a - b)) <= 2e-2 and not np.array_equal(a, b)
+    finally:
+        L.cp360_destroy(h)
+    # Conv1 not a Winograd shape: input + hidden = 1276 is no multiple of 8 -> the whole cell stays on the direct kernels
+    h = C.c_void_p()
+    _lib.check(L.cp360_create(torch.cuda.current_device(), C.byref(h)))
+    try:
+        Cin2 = 1020
+        w1b = g(7827, (c4, Cin2 + Hc, 3, 3), (2.0 / (9 * c4)) ** 0.5)
+        rc = L.cp360_clstm_load(h, code, p(w1b), p(b1), p(w2), p(b2), p(wg), p(bg), Cin2, Hc, w, _lib.stream())
+        if rc == 0:
+            assert L.cp360_clstm_wino_state(h, B, w) == 0
+    finally:
+        L.cp360_destroy(h)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 @pytest.mark.parametrize('n,n_img', [(7, 24), (8, 12), (5, 6), (7, 30), (9, 6)])
 def test_wino_fused_output_input_equals_the_two_kernels(n, n_img, prec):

@@ -8,7 +8,7 @@ for spec in "$@"; do
   D=/tmp/wc_$name; mkdir -p $D
   src=$C/wino.hip
   if [ "$name" = head ] && [ -f $R/tools/_exp/wino_head.hip ]; then cp $R/tools/_exp/wino_head.hip $C/wino_head_tmp.hip; src=$C/wino_head_tmp.hip; fi
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $src -o $D/wino.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DWINO_LAB $flags -c $src -o $D/wino.o || exit 1
   rm -f $C/wino_head_tmp.hip
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so $(ls $C/*.o | grep -v wino.o) $D/wino.o
 done

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 C=$R/cp_360_weakly_supervised_saliency_amd/csrc
 for v in 8 24; do
 D=/tmp/wv_abl$v; mkdir -p $D
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DWINO_ABL=$v -c $C/wino.hip -o $D/wino.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DWINO_LAB -DWINO_ABL=$v -c $C/wino.hip -o $D/wino.o || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so $(ls $C/*.o | grep -v wino.o) $D/wino.o
 done
 for rep in 1 2 3; do

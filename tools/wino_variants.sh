@@ -5,7 +5,7 @@ C=$R/cp_360_weakly_supervised_saliency_amd/csrc
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   D=/tmp/wv_$name; mkdir -p $D
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $flags -c $C/wino.hip -o $D/wino.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DWINO_LAB $flags -c $C/wino.hip -o $D/wino.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libcp360.so $(ls $C/*.o | grep -v wino.o) $D/wino.o
 done
 for rep in 1 2 3; do
