@@ -63,10 +63,13 @@ constexpr bool kTabLate = false, kNtOutIn = true, kNtGates = false;
 // of M and the 49 MB of V between the launches stay in it, and the HEAD of every workgroup's U stream - what all 256 workgroups
 // ask for at once when a launch starts - is still there from the previous cell update (cell update 480 us with everything
 // default, 474 all non-temporal, 454 with the first 4-8 sub-steps default, 460+ from 16 up).
-__device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off, unsigned dst, bool nt) {
+__device__ __forceinline__ void fill_one(const unsigned char* base, unsigned off, unsigned dst, bool is_u, bool u_nt) {
     unsigned keep;
-    if (nt)
+    if (is_u && u_nt)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+    else if (is_u)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
     else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -103,21 +106,27 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
     unsigned rdst = 0;                                            // LDS destination (this wave's slot) of the refill in progress
     int fills = 0;                                                // sub-steps requested so far (uniform)
     // pass q of a sub-step's fill: 0, 1 = the U block's two 128-row passes; 2, 3, 4 = the V block's three
-    auto dma = [&](int q) __attribute__((always_inline)) {
-        const unsigned src = o0 + (unsigned)((q < 2 ? q : q - 2) * 0x2000);
-        fill_one(q < 2 ? ub : vb, src, rdst + (unsigned)(q * 0x2000), q < 2 && fills >= p.u_pin);
+    auto dma = [&](int u) __attribute__((always_inline)) {
+        const int q = u % 5, half = u / 5;
+        const unsigned src = o0 + (unsigned)((q < 2 ? q : q - 2) * 0x2000 + half * 0x1000);
+        fill_one(q < 2 ? ub : vb, src, rdst + (unsigned)(q * 0x2000 + half * 0x1000), q < 2, fills >= p.u_pin);
     };
-    auto refill = [&](int stage) __attribute__((always_inline)) {
+    auto refill_begin = [&](int stage) __attribute__((always_inline)) {
         rdst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * WG_STAGE);
-#pragma unroll
-        for (int q = 0; q < NU; ++q) dma(q);
+    };
+    auto refill_end = [&]() __attribute__((always_inline)) {
         ub += WG_BN * 64;
         vb += vstep;
         ++fills;
     };
 #pragma unroll
     for (int k = 0; k < NS - 1; ++k)
-        if (k < nsub) refill(k);
+        if (k < nsub) {
+            refill_begin(k);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) dma(u);
+            refill_end();
+        }
     int stage = 0;
     u32x4 a[4], b[JH];
     if (LAG) {
@@ -126,51 +135,61 @@ __device__ __forceinline__ void gemm_body(const WinoK& p, unsigned char* lds, co
 #pragma unroll
         for (int j = 0; j < JH; ++j) b[j] = u32x4{0u, 0u, 0u, 0u};
     }
+    // (HEAD / TAIL / STEP are macros, not lambdas: as lambdas the same statements compile to a main loop that measured 2 - 4 %
+    // slower, tools/wino_cell_ab.sh product against laboratory build.)
     // REFILL: the stage read in the PREVIOUS sub-step (every wave finished with it before this sub-step's barrier) takes sub-step
     // it + NS - 1.  A lagging wave's TAIL runs in front of its HEAD: the freed stage is the one behind `stage` there too.
-    auto head = [&](bool do_refill) __attribute__((always_inline)) {
-        const unsigned char* As = lds + stage * WG_STAGE;
-        const unsigned char* Bs = As + WG_BN * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const u32x4*>(As + swz64(wch0 + i * 16 + lrow, lchunk));
-#pragma unroll
-        for (int j = 0; j < JH; ++j) b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + j * 16 + lrow, lchunk));
-        if (do_refill) refill(stage == 0 ? NS - 1 : stage - 1);
-        if (LAG) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < JH; ++j) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);
-            b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + (JH + j) * 16 + lrow, lchunk));
-        }
-        if (LAG) __builtin_amdgcn_s_setprio(0);
-        stage = stage == NS - 1 ? 0 : stage + 1;
-    };
-    auto tail = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = JH; j < MJ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j - JH]);
-    };
-    auto step = [&](bool do_refill) __attribute__((always_inline)) {
-        if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!LAG) head(do_refill); else tail();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!LAG) tail(); else head(do_refill);
-    };
+#define WINO_HEAD(REFILL)                                                                                  \
+    {                                                                                                      \
+        const unsigned char* As = lds + stage * WG_STAGE;                                                  \
+        const unsigned char* Bs = As + WG_BN * 64;                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            a[i] = *reinterpret_cast<const u32x4*>(As + swz64(wch0 + i * 16 + lrow, lchunk));              \
+        _Pragma("unroll") for (int j = 0; j < JH; ++j)                                                     \
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + j * 16 + lrow, lchunk));             \
+        if (REFILL) {                                                                                      \
+            refill_begin(stage == 0 ? NS - 1 : stage - 1);                                                 \
+            _Pragma("unroll") for (int u = 0; u < NU; ++u) dma(u);                                         \
+            refill_end();                                                                                  \
+        }                                                                                                  \
+        if (LAG) __builtin_amdgcn_s_setprio(1);                                                            \
+        _Pragma("unroll") for (int j = 0; j < JH; ++j) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j]);             \
+            b[j] = *reinterpret_cast<const u32x4*>(Bs + swz64(wrow0 + (JH + j) * 16 + lrow, lchunk));      \
+        }                                                                                                  \
+        if (LAG) __builtin_amdgcn_s_setprio(0);                                                            \
+        stage = stage == NS - 1 ? 0 : stage + 1;                                                           \
+    }
+#define WINO_TAIL()                                                                                        \
+    {                                                                                                      \
+        _Pragma("unroll") for (int j = JH; j < MJ; ++j) {                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) mma_chunk<T>(acc[i][j], a[i], b[j - JH]);        \
+        }                                                                                                  \
+    }
+#define WINO_STEP(REFILL)                                                                                  \
+    {                                                                                                      \
+        if (LAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (!LAG) WINO_HEAD(REFILL) else WINO_TAIL()                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (!LAG) WINO_TAIL() else WINO_HEAD(REFILL)                                                       \
+    }
     // vmcnt (DMAs complete in issue order): before sub-step `it` its stage must have landed; younger are the NS - 2 stages behind it
     int it = 0;
     for (; it + NS - 1 < nsub; ++it) {
         vm_wait<(NS - 2) * NU>();
-        step(true);
+        WINO_STEP(true)
     }
     for (; it < nsub; ++it) {
         vm_wait_upto<(NS - 2) * NU>(min(NS - 2, nsub - 1 - it) * NU);
-        step(false);
+        WINO_STEP(false)
     }
-    if (LAG) tail();
+    if (LAG) WINO_TAIL()
+#undef WINO_STEP
+#undef WINO_HEAD
+#undef WINO_TAIL
 
     // slabs: M[pos][tile][channel], a lane owns 4 consecutive channels of one tile per block (16-byte stores).  Tile rows outermost:
     // the four 64-byte pieces of a row's 256 bytes leave back to back and merge into full lines in L2.  Odd faces: the never-read
