@@ -484,6 +484,9 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     }
 }
 
+// (Layer3's 14x14 launch with NB = 2 - one 8-wave workgroup per face, the two bands' waves fetching the same conv2 / conv3 fragments so that
+// the second request hits the CU's L1 - measured 199.5 us against 165.4: 384 workgroups of 152 KB are 1.5 rounds of one workgroup per CU,
+// profiles/r06_l3nb2_ab.log.)
 // (A wave-specialised persistent form of this kernel - waves 0-3 gather + conv2 of band i while waves 4-7 run conv3 +
 // residual + store of band i-1 from the t tile, two workgroup barriers per band - was built for layer3 and measured
 // bit-identical and no faster, 176 vs 175 us: each stage is latency-bound at the waves it has, so halving the waves per

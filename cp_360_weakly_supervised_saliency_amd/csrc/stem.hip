@@ -15,6 +15,7 @@
 // Epilogue: bias + ReLU, one rounding, 16-byte pieces straight to global (acc_chan row order: a lane
 // holds 8 consecutive channels), 128 contiguous bytes per pixel.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -392,6 +393,184 @@ __global__ __launch_bounds__(512) void stem_pool_kernel(const T* __restrict__ xp
     }
 }
 
+// The same stage as TWO workgroups per CU (round 6): a workgroup of 4 waves owns 4 stem rows = 2 pooled rows (+ the halo row above,
+// computed again: 35 MFMA units per band, 9 / 9 / 9 / 8 per wave), ONE patch buffer (15 padded input rows = 27.6 KB) and 70 KB of LDS.
+// stem_pool_kernel's single 8-wave workgroup per CU runs its phases - MFMAs, bias / ReLU / pack / horizontal maximum (VALU), LDS
+// exchange, vertical maximum + stores - strictly one after the other with three workgroup barriers per band (9.8 us per band of
+// which 3.6 are MFMA issue time); here the co-resident workgroup's MFMAs run under this one's VALU / store phases instead.
+namespace {
+constexpr int SQ_PATCH_ROWS = 15, SQ_PATCH_BYTES = SQ_PATCH_ROWS * 1840, SQ_PATCH_INST = 27;
+constexpr int SQ_HBUF = 4 * SP_HROW;                         // four horizontally pooled rows (28,672 B) take the patch's place
+static_assert(SQ_PATCH_INST * 1024 <= SQ_HBUF, "the pooled rows overlay the patch");
+}  // namespace
+
+// (A prefetch form of this kernel - filter fragments from L2 one row ahead instead of from LDS, the 28 KB they free holding a separate
+// pooled-row buffer so that the next band's patch lands under the epilogue - measured 215 us against 199: profiles/r06_stem_ab.log.)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_pool4_kernel(const T* __restrict__ xp, const T* __restrict__ wpk,
+                                                            const float* __restrict__ bias, T* __restrict__ y,
+                                                            T* __restrict__ border, int n_img, int reverse) {
+    constexpr int WP = 230, WO = 112, HO = 56, ROW_BYTES = 1840, BAND = 4, NBAND = WO / BAND;
+    // LDS: filter | patch, later the four pooled rows in its place | raw halo row | 64 biases
+    constexpr int OFF_PATCH = W_BYTES, OFF_HBUF = W_BYTES, OFF_HRAW = OFF_HBUF + SQ_HBUF, OFF_BIAS = OFF_HRAW + 112 * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[OFF_BIAS + 256];
+    static_assert(OFF_BIAS + 256 <= 80 * 1024, "two workgroups per CU");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_base = (unsigned)(size_t)lds;
+    const int ntiles = n_img * NBAND;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xp);
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(wpk);
+    const size_t img_bytes = (size_t)WP * ROW_BYTES;
+    unsigned char* pbuf = lds + OFF_PATCH;
+    unsigned char* hbuf = lds + OFF_HBUF;
+    unsigned char* hraw = lds + OFF_HRAW;
+    float* bias_s = reinterpret_cast<float*>(lds + OFF_BIAS);
+    if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.f;
+
+    // patch of tile t: padded input rows 8 band - 2 .. 8 band + 12 (band 0 has no halo row: its first two patch rows come from the zero line)
+    auto load_patch = [&](int t) __attribute__((always_inline)) {
+        const int tt = reverse ? ntiles - 1 - t : t;
+        const int img = tt / NBAND, band = tt - img * NBAND;
+        const long long row0 = (long long)8 * band - 2;
+        const unsigned char* src0 = xb + (size_t)img * img_bytes + row0 * ROW_BYTES;
+#pragma unroll
+        for (int q = 0; q < (SQ_PATCH_INST + 3) / 4; ++q) {
+            const int inst = wave + 4 * q;
+            if (inst < SQ_PATCH_INST) {
+                const int off = inst * 1024 + lane * 16;
+                const bool ok = off < SQ_PATCH_BYTES && (band > 0 || off >= 2 * ROW_BYTES);
+                const void* src = ok ? (const void*)(src0 + off) : (const void*)s_zero16;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_base + OFF_PATCH + inst * 1024));
+            }
+        }
+    };
+    {   // filter: 28 KiB = 28 instructions, source-side swizzle (as stem_kernel), seven per wave
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int inst = wave + 4 * q;
+            const int row = inst * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((0 - (row >> 2)) & 3);
+            glds16(wb + row * 64 + chunk * 16, __builtin_amdgcn_readfirstlane(lds_base + inst * 1024));
+        }
+    }
+    const int lrow = lane & 15, lchunk = lane >> 4;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tt = reverse ? ntiles - 1 - t : t;
+        const int img = tt / NBAND, band = tt - img * NBAND;
+        __syncthreads();                                           // the previous band's pooled rows (over the patch) have been read
+        load_patch(t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // the patch (and, first time, the filter) landed
+        const bool halo = band > 0;
+        // units 0-6: the seven pixel blocks of stem row 4 band + wave (patch rows 2 (wave + 1) ..); units 7, 8: blocks 2 wave,
+        // 2 wave + 1 of the halo row 4 band - 1 (patch rows 0 ..; wave 3 has block 6 only - its unit 8 repeats it and is dropped)
+        const int hb0 = 2 * wave, hb1 = wave < 3 ? 2 * wave + 1 : 6;
+        f32x4 acc[4][9];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int u = 0; u < 9; ++u) acc[i][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* P = pbuf + (2 * (wave + 1)) * ROW_BYTES + 16 * (lrow + lchunk);
+        const unsigned char* PH0 = pbuf + 16 * (hb0 * 16 + lrow + lchunk);
+        const unsigned char* PH1 = pbuf + 16 * (hb1 * 16 + lrow + lchunk);
+        auto load_w = [&](int ky, u32x4 (&a)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const u32x4*>(lds + w_swz(ky * 64 + i * 16 + lrow, lchunk));
+        };
+#pragma unroll 1
+        for (int ky = 0; ky < 7; ++ky) {
+            u32x4 a[4], b[9];
+            load_w(ky, a);
+#pragma unroll
+            for (int u = 0; u < 7; ++u) b[u] = *reinterpret_cast<const u32x4*>(P + ky * ROW_BYTES + u * 256);
+            b[7] = *reinterpret_cast<const u32x4*>(PH0 + ky * ROW_BYTES);
+            b[8] = *reinterpret_cast<const u32x4*>(PH1 + ky * ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int u = 0; u < 9; ++u) mma<T>(acc[i][u], a[i], b[u]);
+        }
+        __syncthreads();                                           // every wave is done reading the patch
+        // ---- bias + ReLU + one rounding; border copies; horizontal 3-maximum; pooled rows / halo row -> LDS (as stem_pool_kernel)
+        const int srow = band * BAND + wave;                       // this wave's stem row
+        T* bimg = border + (size_t)img * 4 * WO * 64;
+        unsigned char* hrow = hbuf + wave * SP_HROW;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n = pr * 32 + lchunk * 8;
+            float bl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bl[e] = bias_s[n + e];
+            u32x4 o[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(acc[2 * pr][u][e] + bl[e], 0.f);
+                    v[4 + e] = fmaxf(acc[2 * pr + 1][u][e] + bl[4 + e], 0.f);
+                }
+                o[u] = pack8(v, T());
+            }
+            if (srow == 0 || srow == WO - 1) {
+                T* brow = bimg + (size_t)(srow == 0 ? 0 : 1) * WO * 64;
+#pragma unroll
+                for (int u = 0; u < 7; ++u) *reinterpret_cast<u32x4*>(brow + (size_t)(u * 16 + lrow) * 64 + n) = o[u];
+            }
+            if (lrow == 0) *reinterpret_cast<u32x4*>(bimg + ((size_t)2 * WO + srow) * 64 + n) = o[0];
+            if (lrow == 15) *reinterpret_cast<u32x4*>(bimg + ((size_t)3 * WO + srow) * 64 + n) = o[6];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                u32x4 m = o[u];
+                const unsigned* cur = reinterpret_cast<const unsigned*>(&o[u]);
+                const unsigned* prv = reinterpret_cast<const unsigned*>(&o[u > 0 ? u - 1 : 0]);
+                unsigned* mm = reinterpret_cast<unsigned*>(&m);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned right = (unsigned)__builtin_amdgcn_update_dpp(0, (int)cur[d], 0x101, 0xf, 0xf, true);     // row_shl:1
+                    const unsigned wrap = u > 0 ? (unsigned)__builtin_amdgcn_update_dpp(0, (int)prv[d], 0x121, 0xf, 0xf, true) : 0u;
+                    const unsigned left = (unsigned)__builtin_amdgcn_update_dpp((int)wrap, (int)cur[d], 0x111, 0xf, 0xf, false);   // row_shr:1
+                    mm[d] = pkmax(pkmax(cur[d], left), right);
+                }
+                // (chunk ch of pooled pixel px sits at chunk ch ^ (px & 7) of its 128-byte row: the lanes of one store - neighbouring
+                //  pixels, the same chunk - would otherwise all hit the same banks, 4-way for these rows and 8-way for the halo row)
+                if ((lrow & 1) == 0) {
+                    const int px = u * 8 + (lrow >> 1);
+                    *reinterpret_cast<u32x4*>(hrow + px * 128 + (((n >> 3) ^ (px & 7)) << 4)) = m;
+                }
+            }
+            if (halo) {
+                *reinterpret_cast<u32x4*>(hraw + (hb0 * 16 + lrow) * 128 + (((n >> 3) ^ (lrow & 7)) << 4)) = o[7];
+                if (wave < 3) *reinterpret_cast<u32x4*>(hraw + (hb1 * 16 + lrow) * 128 + (((n >> 3) ^ (lrow & 7)) << 4)) = o[8];
+            }
+        }
+        __syncthreads();                                           // the pooled rows (and the halo row) are complete
+        // ---- vertical 3-maximum: pooled row i of the band = stem rows 2i-1 (i = 0: the halo row), 2i, 2i+1
+        T* yimg = y + ((size_t)img * HO + band * 2) * HO * 64;
+        for (int it = tid; it < 2 * HO * 8; it += 256) {
+            const int i = it / (HO * 8), rem = it - i * (HO * 8);
+            const int c = rem >> 3, k = rem & 7;
+            auto hp = [&](int r) __attribute__((always_inline)) -> u32x4 {
+                return *reinterpret_cast<const u32x4*>(hbuf + r * SP_HROW + c * 128 + ((k ^ (c & 7)) << 4));
+            };
+            u32x4 m = pkmax4(hp(2 * i), hp(2 * i + 1));
+            if (i > 0) {
+                m = pkmax4(m, hp(2 * i - 1));
+            } else if (halo) {
+                auto hx = [&](int px) __attribute__((always_inline)) -> u32x4 {
+                    return *reinterpret_cast<const u32x4*>(hraw + px * 128 + ((k ^ (px & 7)) << 4));
+                };
+                m = pkmax4(m, hx(2 * c));
+                m = pkmax4(m, hx(2 * c + 1));
+                if (c > 0) m = pkmax4(m, hx(2 * c - 1));
+            }
+            *reinterpret_cast<u32x4*>(yimg + ((size_t)i * HO + c) * 64 + k * 8) = m;
+        }
+    }
+}
+
 // CubePad(1) of the max-pool: pooled row 0 and column 0 of every face take the maximum with the padding pixels of their
 // windows - padded row -1 / column -1 of the face = border pixels of other faces' stem outputs (cubepad_src).
 template <typename T>
@@ -444,10 +623,19 @@ extern "C" int cp360_stem_pool_forward(int dtype, const void* xp, const void* pa
     const dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
     const int rev = cp360_launch_reverse();
     const int fix_blocks = (n_img * 111 * 8 + 255) / 256;
+    // CP360_STEM_POOL=8: the round-2 form (one 8-wave workgroup per CU, 8 stem rows per band); default: two 4-wave workgroups per CU
+    // (199 against 206 us, profiles/r06_stem_ab.log)
+    static const int form = []() { const char* e = getenv("CP360_STEM_POOL"); return e ? atoi(e) : 4; }();
+    const int ntiles4 = n_img * 28;
+    const dim3 grid4((unsigned)(ntiles4 < 512 ? ntiles4 : 512));
 #define CP360_SP(TT)                                                                                                   \
     {                                                                                                                  \
-        hipLaunchKernelGGL((stem_pool_kernel<TT>), grid, dim3(512), 0, st, (const TT*)xp, (const TT*)packed, bias, (TT*)y, \
-                           (TT*)border, n_img, rev);                                                                   \
+        if (form == 8)                                                                                                 \
+            hipLaunchKernelGGL((stem_pool_kernel<TT>), grid, dim3(512), 0, st, (const TT*)xp, (const TT*)packed, bias, (TT*)y, \
+                               (TT*)border, n_img, rev);                                                               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((stem_pool4_kernel<TT>), grid4, dim3(256), 0, st, (const TT*)xp, (const TT*)packed, bias, (TT*)y, \
+                               (TT*)border, n_img, rev);                                                               \
         hipLaunchKernelGGL((stem_pool_fix_kernel<TT>), dim3((unsigned)fix_blocks), dim3(256), 0, st, (TT*)y,            \
                            (const TT*)border, n_img);                                                                  \
     }
