@@ -1001,8 +1001,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
     if constexpr (BM == 256) {
         if (wave < 4) ring_body<T, 256, 8, 4, false>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 128);
         else          ring_body<T, 256, 8, 4, true>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 128);
+    } else if constexpr (BM == 160) {
+        // (round 6) 160-pixel tile: 5 pixel blocks per wave.  For launches whose 256 / 304-pixel tiles leave a third of the CUs without a
+        // workgroup (layer4's 1x1 and 3x3 convolutions at 64 frames: M = 18816 pixels x 512 channels = 148 tiles of 256 pixels) - 236
+        // tiles of 160 give (nearly) every CU one, without a split-K slab round trip
+        if (wave < 4) ring_body<T, 160, 5, 3, false>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 80);
+        else          ring_body<T, 160, 5, 3, true>(p, lds, n0, m0, split, wave, lane, tid, (wave >> 1) * 64, (wave & 1) * 80);
     } else {
-        static_assert(BM == 304, "pixel tile is 256 or 304");
+        static_assert(BM == 304, "pixel tile is 160, 256 or 304");
         if (wave < 4) ring_body<T, 304, 10, 5, false>(p, lds, n0, m0, split, wave, lane, tid, wave * 64, 0);
         else          ring_body<T, 304, 9, 5, true>(p, lds, n0, m0, split, wave, lane, tid, (wave - 4) * 64, 160);
     }
@@ -1013,6 +1019,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ring_kernel(const ConvK p) 
 // SIMD), so one tile's epilogue traffic overlaps the other's operand loads and MFMAs.  A single
 // 160 KiB-LDS workgroup per CU runs load, compute, residual and store phases strictly one after the
 // other (ablations in DESIGN.md).  Epilogue: direct 16-byte pieces (no LDS).
+// (Three 24 KiB stages instead of two - 72 KiB, still two workgroups per CU - measured the same on the K <= 512 B launches and slower than
+// the 256x304 ring at K = 1 - 2 KiB: 99 / 117 us against 86 / 76 per launch, profiles/r06_ring2_ab.log.)
 template <typename T>
 __global__ __launch_bounds__(512, 4) void conv_igemm_ring2_kernel(const ConvK p) {
     typedef RingGeom<128, 2> G;
@@ -1642,9 +1650,10 @@ static int check_desc(const cp360_conv_desc* d) {
         d->sx <= 0 || d->h_out <= 0 || d->w_out <= 0 || d->c_out <= 0 || d->splits < 1 || d->pix_stride <= 0)
         return CP360_ERR_BAD_SHAPE;
     const int epc = 16 / elem_bytes(d->dtype);
-    if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 256 &&
+    if (d->tile_px != 0 && d->tile_px != 64 && d->tile_px != 128 && d->tile_px != 129 && d->tile_px != 160 && d->tile_px != 256 &&
         d->tile_px != 304 && d->tile_px != 6464)
         return CP360_ERR_BAD_SHAPE;
+    if (d->tile_px == 160 && d->dtype == CP360_F32) return CP360_ERR_UNSUPPORTED;      // the 160-pixel ring tile: 16-bit types
     if (d->tile_px == 6464) {                                  // forced small tile: exactly what the planner requires of it
         const int rc = small_shape_status(d);
         if (rc) return rc;
@@ -1816,6 +1825,15 @@ static ConvPlan plan_big(const cp360_conv_desc* d) {
     }();
     const ConvPlan c = plan_candidate(d, 256, 304, 256, 2.2 * 304.0 / 256.0);   // 19 pixel blocks: 7x7 cube faces
     if (!no304 && c.cost < best.cost) best = c;
+    // 160-pixel tile (16-bit types): wins where the larger tiles cannot give every CU a workgroup
+    static const int use160 = []() {
+        const char* e = getenv("CP360_TILE160");           // A/B switch
+        return e ? atoi(e) : 1;
+    }();
+    if (use160 && d->dtype != CP360_F32 && d->c_in2 == 0) {
+        const ConvPlan t160 = plan_candidate(d, 256, 160, 256, 2.2 * 176.0 / 256.0);
+        if (t160.cost < best.cost) best = t160;
+    }
     // short-K 1x1 convolutions (HBM-bound): 256x128 tile with two workgroups per CU (pixel tile id 129)
     static const int ring2 = []() {
         const char* e = getenv("CP360_RING2");             // A/B switch for tools/bench_conv.py
@@ -1879,6 +1897,8 @@ extern "C" int cp360_conv_prefer_clip(const cp360_conv_desc* d) {
     if (check_desc(&c)) return 0;
     cp360_conv_desc t = c;
     t.clip_resident = 0;
+    static const int force = []() { const char* e = getenv("CP360_PREFER_CLIP"); return e ? atoi(e) : -1; }();   // A/B switch
+    if (force >= 0 && !check_desc(&t)) return force ? 1 : 0;
     if (check_desc(&t) || !small_eligible(&t)) return 1;
     return plan_big(&c).cost <= plan_small(&t).cost ? 1 : 0;
 }
@@ -1910,7 +1930,7 @@ extern "C" int cp360_conv_plan_describe(const cp360_conv_desc* d, char* buf, siz
     } else {
         const int px = bm == 129 ? 128 : bm;
         name = bm == 129 ? "conv_igemm_ring2 256 ch x 128 px (two workgroups per CU)"
-               : bm == 304 ? "conv_igemm_ring 256 ch x 304 px" : bm >= 256 ? "conv_igemm_ring 256 ch x 256 px" : "conv_igemm_dma 256 ch x 128 px";
+               : bm == 304 ? "conv_igemm_ring 256 ch x 304 px" : bm == 160 ? "conv_igemm_ring 256 ch x 160 px" : bm >= 256 ? "conv_igemm_ring 256 ch x 256 px" : "conv_igemm_dma 256 ch x 128 px";
         wgs = (long long)((t.c_out + 255) / 256) * ((M + px - 1) / px);
     }
     const int n = snprintf(buf, cap, "%s, %lld workgroups x split-K %d%s, model %.0f us", name, wgs * pl.splits, pl.splits,
@@ -2098,6 +2118,7 @@ extern "C" int cp360_conv_forward2(const cp360_conv_desc* d, const void* in, con
 #define CP360_WIDE(TT)                                                                                     \
         {                                                                                                      \
             if (bm == 304) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 304>), grid, dim3(512), 0, st, k);   \
+            else if (bm == 160) { if constexpr (sizeof(TT) == 2) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 160>), grid, dim3(512), 0, st, k); } \
             else if (big && ring) hipLaunchKernelGGL((conv_igemm_ring_kernel<TT, 256>), grid, dim3(512), 0, st, k); \
             else if (big) hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 8>), grid, dim3(512), 0, st, k);       \
             else          hipLaunchKernelGGL((conv_igemm_dma_kernel<TT, 4>), grid, dim3(512), 0, st, k);       \

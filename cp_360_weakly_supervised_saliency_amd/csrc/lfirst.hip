@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void lf_pack_w3d_kernel(const float* __restric
     else packed[idx] = f32_to_bf16(v);
 }
 
+// (Round 6: a 56-pixel band streams 816 KB of conv2 / conv3 + downsample / next-conv1 fragments from L2 - 4.4 GB per 64-frame launch.  A form with
+// TWO bands per 8-wave workgroup, the two wave sets requesting the same fragments at about the same time so that the second request
+// could be served by the CU's L1, measured 405 us against 355: the requests do not merge, and one 152 KB workgroup per CU hides less
+// than two independent ones.  profiles/r06_l2first_nb_ab.log)
 template <typename T, bool NEXT>
 __global__ __launch_bounds__(256, 2) void l2first_kernel(const T* __restrict__ mid, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3df,

@@ -788,6 +788,33 @@ def test_wide_conv_forced_pixel_tiles(tile_px, prec, splits):
     assert rel_err(got, want) <= _TOL[prec], rel_err(got, want)
 
 
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('geom', [(12, 96, 264, 7, 3, 1, 1), (12, 96, 264, 7, 3, 1, 3), (6, 512, 512, 14, 1, 1, 1), (6, 128, 256, 14, 3, 2, 1)])
+def test_wide_conv_160_pixel_tile(prec, geom):
+    """tile_px = 160 (round 6): the 256-channel x 160-pixel ring tile (5 pixel blocks per wave, two waves issue the partial DMA
+    pass of 32 rows) - what the planner takes when the 256 / 304-pixel tiles leave CUs without a workgroup (layer4 at 64 frames).
+    3x3 CubePad and 1x1 and stride-2 geometries, a ragged last tile (588 / 1176 / 294 pixels), a ragged channel tile (264), residual +
+    ReLU through the LDS epilogue, split-K slabs; f32 is refused."""
+    dt = _TDT[prec]
+    n_img, cin, cout, n, k, st, splits = geom
+    x = hashrng.normal(9310, (n_img, cin, n, n))
+    w = hashrng.normal(9311, (cout, cin, k, k), 0, (2.0 / (k * k * cin)) ** 0.5)
+    bias = hashrng.normal(9313, (cout,), 0, 0.1)
+    no = (n + 2 * (k // 2) - k) // st + 1
+    res = hashrng.normal(9314, (n_img, cout, no, no))
+    rb = lambda a: torch.from_numpy(a).to(dt).float().numpy()
+    want = _conv_ref(rb(x), rb(w), None, bias, st, k // 2, True, rb(res))
+    conv = ops.Conv(torch.from_numpy(w), None, torch.from_numpy(bias), st, k // 2, True, dt, DEV)
+    xt = ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=dt)
+    rt = ops.nchw_to_nhwc(torch.from_numpy(res).to(DEV), out_dtype=dt)
+    got = ops.nhwc_to_nchw(conv(xt, residual=rt, splits=splits, tile_px=160), out_dtype=torch.float32).cpu().numpy()
+    assert got.shape == want.shape and rel_err(got, want) <= _TOL[prec], rel_err(got, want)
+    if geom == (12, 96, 264, 7, 3, 1, 1):
+        c32 = ops.Conv(torch.from_numpy(w), None, torch.from_numpy(bias), 1, 1, True, torch.float32, DEV)
+        with pytest.raises(Exception):
+            c32(ops.nchw_to_nhwc(torch.from_numpy(x).to(DEV), out_dtype=torch.float32), tile_px=160)
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('cin', [64, 200])
 @pytest.mark.parametrize('use_res', [False, True])
