@@ -141,6 +141,19 @@ __global__ __launch_bounds__(256) void bt_pack_kernel(const float* __restrict__ 
     else packed[idx] = f32_to_bf16(v);
 }
 
+// Diagnostic build only (-DL2_STAMPS, tools/l2_stamps.sh): s_memtime stamps of wave 0 of every workgroup at the phase boundaries (0 start,
+// 1 patch landed + barrier, 2 + hc conv2 of channel half hc done, 4 t tile complete + barrier, 5 + q after pass q of stage 3, 15 end); the
+// product build executes no stamp.
+#ifdef L2_STAMPS
+__device__ unsigned long long g_l2_stamps[8192 * 16];
+#define L2_STAMP(k)                                                                                         \
+    { __builtin_amdgcn_sched_barrier(0);                                                                    \
+      if (wave == 0 && lane == 0 && blockIdx.x < 8192) g_l2_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+      __builtin_amdgcn_sched_barrier(0); }
+#else
+#define L2_STAMP(k)
+#endif
+
 template <typename T, int CV, int NB, int NV, int BANDV, bool NEXT>
 __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
@@ -154,7 +167,10 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
                   KK = G::KK, HC = G::HC, SPT = G::SPT, STEPS = G::STEPS, KB3 = G::KB3, H3 = G::H3, PASSES = G::PASSES,
                   OFF_BIAS = NEXT ? G::OFF_BIAS_NEXT : G::OFF_BIAS;
     static_assert(!NEXT || CV == 128, "the chained conv1 exists for layer2");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NEXT ? G::LDS_BYTES_NEXT : G::LDS_BYTES];
+#ifndef L2_LDS_PAD
+#define L2_LDS_PAD 0                                               // (diagnostic builds: > 0 pushes the launch to ONE workgroup per CU)
+#endif
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[(NEXT ? G::LDS_BYTES_NEXT : G::LDS_BYTES) + L2_LDS_PAD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half_wg = wave >> 2, w4 = wave & 3;              // band A / B of this workgroup, wave inside the band
@@ -166,6 +182,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     const int lrow = lane & 15, lchunk = lane >> 4;
     const size_t pix0 = (size_t)gband * PXV;                   // the band's first pixel (pixels of a band are consecutive)
     unsigned char* patch = lds + half_wg * PATCH_LDS;
+    L2_STAMP(0)
 
     // ---- stage 1: gather the band's padded pixels: instruction i = patch pixels PPI i .. PPI i + PPI - 1 (4 x 256 B / 2 x 512 B)
     {
@@ -218,6 +235,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
         if (hc == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch DMAs (and the first fragments)
             __syncthreads();
+            L2_STAMP(1)
         }
         // B fragments are read one GROUP ahead of the MFMAs that use them (two register sets; a group = up to JG pixel
         // blocks of one k-block): the LDS latency of a group's reads hides under the previous group's MFMAs instead of in
@@ -269,6 +287,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
 #undef CP360_BT_STEP
 #undef CP360_BT_GROUP
 #undef CP360_BT_READ
+        L2_STAMP(2 + hc)
         // ---- stage 2: t = relu(conv2 + b2), rounded once -> the band's t tile (in place of its patch, once every wave
         // is done with the patch: after the LAST channel half)
         if (hc == HC - 1) __syncthreads();
@@ -322,6 +341,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
     load_a3(0, a3);
     load_res(w4, r);                                           // (requested before conv2 instead, next to the patch DMAs: 2-4 % slower; +8 % in l1block)
     __syncthreads();                                           // the t tiles and the biases are complete
+    L2_STAMP(4)
     // conv3's accumulators: the first two rows of conv2's (dead by now)
     if constexpr (!NEXT) {
     // (layer3's 14x14 form runs its 16 half passes four at a time: 178 -> 171 us - the rolled loop rotates the prefetched
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
 #pragma unroll
                 for (int j = 0; j < PB; ++j) r[j] = rn[j];
             }
+            L2_STAMP(5 + q)
         }
         if (u + 1 < PASSES * H3) {
 #pragma unroll
@@ -482,7 +503,14 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
             *reinterpret_cast<u32x4*>(out_next + (pix0 + j * 16 + lrow3) * C + n1) = pack8(v, T());
         }
     }
+    L2_STAMP(15)
 }
+
+#ifdef L2_STAMPS
+extern "C" int cp360_l2_stamps_read(unsigned long long* host) {      // diagnostic build only
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_l2_stamps), sizeof(g_l2_stamps)) == hipSuccess ? 0 : CP360_ERR_HIP;
+}
+#endif
 
 // (Layer3's 14x14 launch with NB = 2 - one 8-wave workgroup per face, the two bands' waves fetching the same conv2 / conv3 fragments so that
 // the second request hits the CU's L1 - measured 199.5 us against 165.4: 384 workgroups of 152 KB are 1.5 rounds of one workgroup per CU,
