@@ -269,6 +269,11 @@ __global__ __launch_bounds__(256 * NB, 2) void l2block_kernel(const T* __restric
             CP360_BT_GROUP(3, S, SLOT, POFF, KOFF, SUB)                                                       \
         }
         if constexpr (SPT % (DEPTH + 1) == 0) {                // layer3: 4 steps per tap, the tap loop stays rolled
+            // (Round 6: carrying the read-ahead of the B fragments across steps and taps - the last group of a step reading the first group of
+            // the next - changed nothing: 167 against 165 us, conv2 of a band alone on its CU 29.2 k instead of 30.3 k cycles per channel half for
+            // 16.1 k of MFMA issue.  Alone, a wave's stream is ISSUE-bound (per 64-byte step 28 MFMAs leave 224 issue cycles for 14 LDS reads, 4
+            // global loads and ~20 vector instructions); with two workgroups per CU the partner's issue slots fill the matrix pipe to ~90 % in this
+            // phase: profiles/r06_l2block_l3_phases*.txt.)
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
