@@ -173,8 +173,10 @@ typedef struct {
     int relu;
     int splits;       /* split-K factor (>= 1); > 1 needs `partial`               */
     int tile_px;      /* 0: the library's launch planner picks the tile; for c_out >=
-                         256 (tuning, tests): 128 / 256 / 304 force the pixel tile
-                         of the 8-wave 256-channel kernels (129 = the 256x128 short-K
+                         256 (tuning, tests): 128 / 160 / 256 / 304 force the pixel tile
+                         of the 8-wave 256-channel kernels (160: 16-bit types only - the
+                         tile the planner takes when the larger ones leave CUs without
+                         a workgroup; 129 = the 256x128 short-K
                          kernel that runs two workgroups per CU), 64 forces the
                          4-wave 128x128 kernel; any c_out % 8 == 0: 6464 forces the
                          64 x 64-tile small-M kernel (csrc/conv_small.hip), which the

@@ -932,10 +932,11 @@ def test_stem_resident_patch_kernel_cube224(prec):
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 @pytest.mark.parametrize('order', [0, 1])
 def test_stem_pool_fused_kernel_bit_exact(prec, order):
-    """csrc/stem.hip stem_pool_kernel (+ stem_pool_fix_kernel): stem conv + BN + ReLU -> CubePad(1) -> max-pool 3x3 s2 in
-    one kernel at cube 224 must equal the two-kernel path (resident stem, then cubepad_maxpool3s2) bit for bit - the
-    same MFMA order per output and maxima of identical values; 12 faces (every band of a face in its own workgroup) and
-    300 faces (4200 band tiles on 256 persistent workgroups: the double-buffered loop, several cubes), both launch orders."""
+    """csrc/stem.hip stem_pool4_kernel (round 6: two 4-wave workgroups per CU, 4 stem rows per band; + stem_pool_fix_kernel): stem
+    conv + BN + ReLU -> CubePad(1) -> max-pool 3x3 s2 in one kernel at cube 224 must equal the two-kernel path (resident stem,
+    then cubepad_maxpool3s2) bit for bit - the same MFMA order per output and maxima of identical values; 12 faces (every band of
+    a face in its own workgroup) and 300 faces (8400 band tiles on 512 persistent workgroups, several cubes), both launch orders.
+    The 8-wave form of rounds 2-5 (CP360_STEM_POOL=8, read once per process): test_stem_pool_8wave_form_bit_exact."""
     dt = _TDT[prec]
     w = hashrng.normal(9641, (64, 3, 7, 7), 0, (2.0 / (49 * 64)) ** 0.5)
     scale = hashrng.uniform(9642, (64,), 0.5, 1.5)
@@ -956,6 +957,19 @@ def test_stem_pool_fused_kernel_bit_exact(prec, order):
         assert got is not None and got.shape == want.shape == (n_img, 56, 56, 64)
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), \
             int((got.view(torch.int16) != want.view(torch.int16)).sum())
+
+
+def test_stem_pool_8wave_form_bit_exact():
+    """CP360_STEM_POOL=8: stem_pool_kernel (one 8-wave workgroup per CU, double-buffered patch) stays buildable for A/B and must give
+    the same bits - the test above in a child process with the switch set."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from tests import test_gpu_parity as t; t.test_stem_pool_fused_kernel_bit_exact('fp16', 0); t.test_stem_pool_fused_kernel_bit_exact('bf16', 1)"
+    e = dict(os.environ, CP360_STEM_POOL='8')
+    e['PYTHONPATH'] = root + os.pathsep + e.get('PYTHONPATH', '')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
