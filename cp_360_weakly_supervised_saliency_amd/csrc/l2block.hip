@@ -520,6 +520,9 @@ extern "C" int cp360_l2_stamps_read(unsigned long long* host) {      // diagnost
 // (Layer3's 14x14 launch with NB = 2 - one 8-wave workgroup per face, the two bands' waves fetching the same conv2 / conv3 fragments so that
 // the second request hits the CU's L1 - measured 199.5 us against 165.4: 384 workgroups of 152 KB are 1.5 rounds of one workgroup per CU,
 // profiles/r06_l3nb2_ab.log.)
+// (Round 6, the 1.5 rounds of layer3's 768 bands on 512 slots: running the last 256 bands as 512 HALF JOBS - two workgroups per band, both gathering the
+// band and running conv2, each running half of stage 3's passes, so that every slot gets one whole band and one half job - measured 189 against 170 us:
+// the second conv2 costs more than the idle slots of the last round, profiles/r06_l3_halfjobs_ab.log.)
 // (A wave-specialised persistent form of this kernel - waves 0-3 gather + conv2 of band i while waves 4-7 run conv3 +
 // residual + store of band i-1 from the t tile, two workgroup barriers per band - was built for layer3 and measured
 // bit-identical and no faster, 176 vs 175 us: each stage is latency-bound at the waves it has, so halving the waves per
