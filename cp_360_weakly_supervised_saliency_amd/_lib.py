@@ -52,7 +52,7 @@ PUBLIC_SYMBOLS = [
 INTERNAL_SYMBOLS = [
     'cp360_stem_packed_bytes', 'cp360_stem_pack_weights', 'cp360_stem_forward', 'cp360_band3x3_packed_bytes',
     'cp360_band3x3_pack_weights', 'cp360_band3x3_forward', 'cp360_frag_packed_bytes', 'cp360_frag_pack_1x1',
-    'cp360_l1block_forward', 'cp360_l1block_forward_wide', 'cp360_l1block_conv2_bytes', 'cp360_l1block_pack_conv2',
+    'cp360_l1block_forward', 'cp360_l1block_forward_wide', 'cp360_l1block_forward_first', 'cp360_l1block_conv2_bytes', 'cp360_l1block_pack_conv2',
     'cp360_l2block_packed_bytes', 'cp360_l2block_pack_weights', 'cp360_l2block_forward',
     'cp360_l2block_forward_next', 'cp360_set_launch_order', 'cp360_stem_pool_border_bytes',
     'cp360_stem_pool_forward', 'cp360_l3block_packed_bytes', 'cp360_l3block_pack_weights', 'cp360_l3block_forward',
@@ -143,6 +143,7 @@ def lib():
     L.cp360_frag_pack_1x1.argtypes = [i, vp, vp, vp, i, i, i, vp]
     L.cp360_l1block_forward.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.cp360_l1block_forward_wide.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.cp360_l1block_forward_first.argtypes = [i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.cp360_l2block_packed_bytes.restype = sz
     L.cp360_l2block_packed_bytes.argtypes = [i]
     L.cp360_l2block_pack_weights.argtypes = [i, vp, vp, vp, vp]

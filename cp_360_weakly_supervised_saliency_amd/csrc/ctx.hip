@@ -229,6 +229,8 @@ struct CBlock {
     // fused-tail packings (16-bit types): layer1 K3d, layer2 / layer3 K3e
     void *w2 = nullptr, *w3f = nullptr, *wdf = nullptr, *w1f = nullptr;   // w1f: the chained NEXT conv1's fragments
     float *b2 = nullptr, *b3 = nullptr, *b1n = nullptr;
+    void* w0f = nullptr;                          // layer1.0: its OWN conv1's fragments (run inside the tail kernel at 56x56 faces)
+    float* b0 = nullptr;
     int next_c = 0;
 };
 
@@ -410,6 +412,11 @@ extern "C" int cp360_resnet_load(cp360_ctx* ctx, int dtype, const cp360_conv_bn*
                 if (B.has_ds) {
                     if (!(B.wdf = own.take(cp360_frag_packed_bytes(dtype, 256, 64)))) return CP360_ERR_HIP;
                     if ((rc = cp360_frag_pack_1x1(dtype, pd->weight, fd.scale, B.wdf, 256, 64, 0, st))) return rc;
+                    if (b == 0 && inplanes == 64 && planes == 64) {       // the block's own conv1 (64 -> 64) for the in-patch form
+                        if (!(B.w0f = own.take(cp360_frag_packed_bytes(dtype, 64, 64)))) return CP360_ERR_HIP;
+                        if ((rc = cp360_frag_pack_1x1(dtype, p1.weight, f1.scale, B.w0f, 64, 64, 0, st))) return rc;
+                        B.b0 = f1.bias;
+                    }
                 }
             } else if (h16 && L == 1 && B.has_ds) {          // layer2.0 after its conv1 as one launch (K3f, 56x56 -> 28x28 faces)
                 if (!(B.w2 = own.take(cp360_l2block_packed_bytes(dtype)))) return CP360_ERR_HIP;
@@ -549,14 +556,23 @@ int resnet_run(cp360_ctx* ctx, bool dry, const void* faces_p3, int n_img, int cd
     {
         std::vector<CBlock>& Lr = R.layer[0];
         if (h16 && (face == 56 || face == 128)) {
-            run.note("layer1: conv1 of block 0, then ONE fused launch per Bottleneck (K3d: conv2 + conv3 + residual / downsample + the next conv1)");
+            // CP360_L1_FIRST=0: conv1 of block 0 as its own launch (the form of rounds 2-5; A/B) instead of inside the block's tail kernel
+            static const int first_env = []() { const char* e = getenv("CP360_L1_FIRST"); return e ? atoi(e) : 1; }();
+            const bool first_in = first_env && face == 56 && Lr[0].w0f != nullptr;
+            run.note(first_in ? "layer1: ONE fused launch per Bottleneck (K3d: [block 0: its conv1 on the resident patch +] conv2 + conv3 + residual / downsample + the next conv1)"
+                              : "layer1: conv1 of block 0, then ONE fused launch per Bottleneck (K3d: conv2 + conv3 + residual / downsample + the next conv1)");
             at(1, 0);
-            // conv1 of the first block, then ONE launch per Bottleneck (K3d); the chained conv1 output ping-pongs
-            CK(run.conv(Lr[0].c1, buf[cur], n_img, face, face, nullptr, 0, other(1), 0, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr));
+            // conv1 of the first block (its own launch, or inside the tail kernel), then ONE launch per Bottleneck (K3d); the chained conv1 output ping-pongs
+            if (!first_in)
+                CK(run.conv(Lr[0].c1, buf[cur], n_img, face, face, nullptr, 0, other(1), 0, 0, nullptr, 0, 0, 0, false, false, nullptr, 0, nullptr));
             if (!dry) {
                 // x = buf[cur] (64 ch), mid = other(1); out -> other(2), mid' -> other(3)
-                CK(cp360_l1block_forward(dtype, other(1), Lr[0].w2, Lr[0].b2, Lr[0].w3f, Lr[0].b3, nullptr, buf[cur], Lr[0].wdf,
-                                         other(2), Lr[0].w1f, Lr[0].b1n, other(3), n_img, face, st));
+                if (first_in)
+                    CK(cp360_l1block_forward_first(dtype, buf[cur], Lr[0].w0f, Lr[0].b0, Lr[0].w2, Lr[0].b2, Lr[0].w3f, Lr[0].b3, Lr[0].wdf,
+                                                   other(2), Lr[0].w1f, Lr[0].b1n, other(3), n_img, face, st));
+                else
+                    CK(cp360_l1block_forward(dtype, other(1), Lr[0].w2, Lr[0].b2, Lr[0].w3f, Lr[0].b3, nullptr, buf[cur], Lr[0].wdf,
+                                             other(2), Lr[0].w1f, Lr[0].b1n, other(3), n_img, face, st));
                 // from here: out = other(2), mid = other(3); free: buf[cur], other(1)
                 unsigned char *o = other(2), *m = other(3), *f0 = buf[cur], *f1 = other(1);
                 for (size_t b = 1; b < Lr.size(); ++b) {

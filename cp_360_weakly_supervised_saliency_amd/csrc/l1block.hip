@@ -142,7 +142,10 @@ __global__ __launch_bounds__(256) void frag_pack_kernel(const float* __restrict_
         const int R = rb * 16 + (lane & 15);
         const int n = row_chan(R);
         const int kk = kb * 32 + (lane >> 4) * 8 + e;
-        const float v = w[(size_t)n * k + kk] * (scale ? scale[n] : 1.f);
+        // (__fmul_rn: the f32 product is rounded BEFORE the 16-bit conversion, as in conv_igemm.hip's pack_weights_kernel - left to the
+        //  compiler the multiply and the f16 conversion become one mixed-precision instruction with a single rounding, and 2 of layer1.0's
+        //  4096 conv1 weights land on the other side of a tie: the in-patch conv1 must use the bits the separate launch uses)
+        const float v = scale ? __fmul_rn(w[(size_t)n * k + kk], scale[n]) : w[(size_t)n * k + kk];
         if constexpr (__is_same(T, f16_raw)) packed[idx] = (f16_raw)v;
         else packed[idx] = f32_to_bf16(v);
     }
@@ -161,14 +164,20 @@ __device__ unsigned long long g_l1_stamps[8192 * 16];
 #define L1_STAMP(k)
 #endif
 
-template <typename T, bool DS, bool NEXT, int NV, int BANDV>
+// FIRST (round 6; layer1.0, with DS): `x` is the BLOCK INPUT (the pooled stem output, 64 channels) instead of conv1's output - the block's own
+// conv1 (1x1, 64 -> 64, + bn1 + relu, model/resnet_cubic.py:88-90) runs on the resident patch IN PLACE between the gather and conv2 (22 pixel
+// blocks x 8 MFMAs per band, halo pixels computed again by the neighbouring bands with the same arithmetic: the same bits as the separate
+// launch), so that launch (conv_pw64_kernel: 59 us, 154 MB read + 154 MB written per 64 frames) and its tensor do not exist.
+template <typename T, bool DS, bool NEXT, int NV, int BANDV, bool FIRST = false>
 __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x, const T* __restrict__ wpk2,
                                                          const float* __restrict__ bias2, const T* __restrict__ w3f,
                                                          const float* __restrict__ bias3, const T* __restrict__ res,
                                                          const T* __restrict__ xds, const T* __restrict__ wdf,
                                                          T* __restrict__ out, const T* __restrict__ w1f,
                                                          const float* __restrict__ bias1, T* __restrict__ out_next,
-                                                         int reverse) {
+                                                         int reverse, const T* __restrict__ w0f = nullptr,
+                                                         const float* __restrict__ bias0 = nullptr) {
+    static_assert(!FIRST || DS, "the in-patch conv1 exists for the first block (downsample form)");
     typedef L1Geom<NV, BANDV> G;
     constexpr int N = G::N, NP = G::NP, BAND = G::BAND, WPR = G::WPR, PATCH_PX = G::PATCH_PX, PATCH_INST = G::PATCH_INST;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS_BYTES];
@@ -219,6 +228,48 @@ __global__ __launch_bounds__(256, 2) void l1block_kernel(const T* __restrict__ x
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the patch DMAs (and the first fragments)
     __syncthreads();
+    if constexpr (FIRST) {
+        // conv1 on the patch, in place: pixel block b = patch pixels 16 b .. 16 b + 15 (wave w takes b = w, w + 4, ...); a lane reads the two
+        // k-block pieces of its pixel and writes the two 8-channel pieces it ends up holding into the same two slots of that pixel
+        u32x4 a0[4][2];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                a0[rb][kb] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(w0f) + ((rb * 2 + kb) * 64 + lane) * 16);
+        float b0[2][8];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b0[pr][e] = bias0 ? bias0[pr * 32 + lchunk * 8 + e] : 0.f;
+        static_assert(!FIRST || PATCH_INST % 2 == 0, "whole 16-pixel blocks");
+#pragma unroll 1
+        for (int blk = wave; blk < PATCH_INST / 2; blk += 4) {
+            const int q = blk * 16 + lrow;
+            unsigned char* px = lds + q * 128;
+            u32x4 b[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) b[kb] = *reinterpret_cast<const u32x4*>(px + (((kb * 4 + lchunk) ^ px_swz(q)) << 4));
+            f32x4 c[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) c[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) mma<T>(c[rb], a0[rb][kb], b[kb]);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(c[2 * pr][e] + b0[pr][e], 0.f);
+                    v[4 + e] = fmaxf(c[2 * pr + 1][e] + b0[pr][4 + e], 0.f);
+                }
+                *reinterpret_cast<u32x4*>(px + (((pr * 4 + lchunk) ^ px_swz(q)) << 4)) = pack8(v, T());
+            }
+        }
+        __syncthreads();                                       // every pixel of the patch is conv1's output now
+    }
     L1_STAMP(1)
 
 #pragma unroll
@@ -757,6 +808,32 @@ extern "C" int cp360_l1block_forward(int dtype, const void* mid, const void* w2_
 #undef CP360_L1B_T
 #undef CP360_L1B_F
 #undef CP360_L1B
+    CP360_CHECK_HIP();
+    return CP360_OK;
+}
+
+// layer1.0 with its own conv1 inside (FIRST): x = the block input [n_img, 56, 56, 64] (conv1's input AND the downsample source),
+// w0_frags = cp360_frag_pack_1x1(w1 [64, 64], order 0) with bn1 folded, bias0 f32 [64]; the other arguments as cp360_l1block_forward's
+// downsample form.  56x56 faces only (cube 224).
+extern "C" int cp360_l1block_forward_first(int dtype, const void* x, const void* w0_frags, const float* bias0, const void* w2_packed,
+                                           const float* bias2, const void* w3_frags, const float* bias3, const void* wd_frags, void* out,
+                                           const void* w1_frags, const float* bias1, void* out_next, int n_img, int face, void* stream) {
+    if (!x || !w0_frags || !w2_packed || !w3_frags || !bias3 || !wd_frags || !out) return CP360_ERR_NULL;
+    if ((w1_frags != nullptr) != (out_next != nullptr)) return CP360_ERR_NULL;
+    if (n_img <= 0) return CP360_ERR_BAD_SHAPE;
+    if (n_img % 6 != 0) return CP360_ERR_BATCH_NOT_6N;
+    if (face != 56) return CP360_ERR_UNSUPPORTED;                                 // other sizes: conv1 as its own launch + cp360_l1block_forward
+    if ((long long)n_img * face * face * CO >= (1LL << 31)) return CP360_ERR_BAD_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define CP360_L1F(TT, NX)                                                                                        \
+    hipLaunchKernelGGL((l1block_kernel<TT, true, NX, 56, 4, true>), dim3((unsigned)(n_img * 14)), dim3(256), 0, st,  \
+                       (const TT*)x, (const TT*)w2_packed, bias2, (const TT*)w3_frags, bias3, (const TT*)nullptr,   \
+                       (const TT*)x, (const TT*)wd_frags, (TT*)out, (const TT*)w1_frags, bias1, (TT*)out_next,      \
+                       cp360_launch_reverse(), (const TT*)w0_frags, bias0)
+    if (dtype == CP360_BF16) { if (w1_frags) CP360_L1F(bf16_raw, true); else CP360_L1F(bf16_raw, false); }
+    else if (dtype == CP360_F16) { if (w1_frags) CP360_L1F(f16_raw, true); else CP360_L1F(f16_raw, false); }
+    else return CP360_ERR_BAD_DTYPE;
+#undef CP360_L1F
     CP360_CHECK_HIP();
     return CP360_OK;
 }

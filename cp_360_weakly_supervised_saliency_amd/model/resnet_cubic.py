@@ -35,6 +35,7 @@ LAUNCH_ORDER = int(os.environ.get('CP360_LAUNCH_ORDER', '2'))   # 0: every launc
 FUSE_LAYER2_NEXT = True    # the next identity block's conv1 chained onto the layer2 tail kernel (csrc/l2block.hip, NEXT)
 FUSE_L2_FIRST = True       # layer2.0 after its conv1 as one launch (csrc/lfirst.hip): stride-2 conv2 -> conv3 + downsample
 CHAIN_L1_L2 = True         # layer2.0's conv1 (256 -> 128) chained onto layer1's last tail kernel (csrc/l1block.hip, wide)
+FUSE_L1_FIRST = os.environ.get('CP360_L1_FIRST', '1') != '0'   # layer1.0's own conv1 inside its tail kernel (csrc/l1block.hip, FIRST); 0 = its own launch
 
 
 
@@ -227,7 +228,8 @@ class ResNet(nn.Module):
                 nxt = c(blks[k + 1].conv1, blks[k + 1].bn1) if k + 1 < len(blks) else \
                     (c(l2c.conv1, l2c.bn1) if chain2 else None)
                 ds = c(b.downsample[0], b.downsample[1]) if b.downsample is not None else None
-                out.append(ops.L1Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), ds, nxt, dt, dev))
+                own = c(b.conv1, b.bn1) if (k == 0 and ds is not None and tuple(b.conv1.weight.shape[:2]) == (64, 64)) else None
+                out.append(ops.L1Block(c(b.conv2, b.bn2), c(b.conv3, b.bn3), ds, nxt, dt, dev, own_conv1=own))
             self._l1, self._l1_stamp = out, stamp
         return self._l1
 
@@ -249,8 +251,11 @@ class ResNet(nn.Module):
                 x = blk.forward_nhwc(x)
             return x, None
         fused = self._layer1_fused()
-        mid = blks[0]._plans()['c1'](x)
-        out, mid = fused[0](mid, x_ds=x)
+        if FUSE_L1_FIRST and x.shape[1] == 56 and fused[0].w0 is not None:
+            out, mid = fused[0].first(x)               # block 0's conv1 inside its tail kernel (round 6)
+        else:
+            mid = blks[0]._plans()['c1'](x)
+            out, mid = fused[0](mid, x_ds=x)
         for k in range(1, len(blks)):
             out, mid = fused[k](mid, residual=out)
         return out, mid                               # mid: layer2.0's conv1 output (CHAIN_L1_L2), else None

@@ -494,7 +494,7 @@ class L1Block:
     conv3 + bn3 + (residual | downsample(x)) + relu -> optionally the next block's conv1 + bn1 + relu.
     16-bit types, 56x56 faces.  Arguments: (weight, bn scale, bn bias) triples of the convolutions."""
 
-    def __init__(self, conv2, conv3, downsample=None, next_conv1=None, dtype=torch.float16, device='cuda'):
+    def __init__(self, conv2, conv3, downsample=None, next_conv1=None, dtype=torch.float16, device='cuda', own_conv1=None):
         if dtype not in (torch.float16, torch.bfloat16):
             raise ValueError("L1Block runs in fp16 / bf16")
         self.dtype, self.device = dtype, torch.device(device)
@@ -516,6 +516,14 @@ class L1Block:
                 raise ValueError("layer1's downsample is 64->256, stride 1")
             self.wd = frag_pack_1x1(wd, sd, dtype, 0, self.device)
             self.b3 = (self.b3 + f32(bd)).contiguous()
+        # own_conv1 (the first block): the block's OWN conv1 (64 -> 64) for first(): it then runs inside the kernel, on the resident patch
+        self.w0 = self.b0 = None
+        if own_conv1 is not None:
+            w0, s0, b0 = own_conv1
+            if tuple(w0.shape[:2]) != (64, 64) or downsample is None:
+                raise ValueError("own_conv1 is layer1.0's conv1 (64 -> 64) and goes with the downsample form")
+            self.w0 = frag_pack_1x1(w0, s0, dtype, 0, self.device)
+            self.b0 = f32(b0)
         self.w1 = self.b1 = None
         self.next_c = 0
         if next_conv1 is not None:
@@ -553,6 +561,23 @@ class L1Block:
         check(lib().cp360_l1block_forward(dtype_code(self.dtype), ptr(mid), ptr(self.w2), ptr(self.b2), ptr(self.w3),
                                           ptr(self.b3), ptr(residual), ptr(x_ds), ptr(self.wd), ptr(out), ptr(self.w1),
                                           ptr(self.b1), ptr(nxt), n_img, n, stream()))
+        return out, nxt
+
+    def first(self, x):
+        """layer1.0 with its own conv1 inside the kernel (cp360_l1block_forward_first): x [n_img, 56, 56, 64] = the block input (conv1's
+        input and the downsample source).  Returns (out, next conv1's output or None); same bits as conv1 as a launch + __call__."""
+        require_gpu(x)
+        if self.w0 is None or self.wd is None:
+            raise ValueError("first() needs own_conv1= and downsample=")
+        n_img, n = x.shape[0], x.shape[1]
+        if n != 56:
+            raise ValueError("the in-kernel conv1 exists for 56x56 faces")
+        _check_buf('x', x, self.dtype, (n_img, n, n, 64))
+        out = torch.empty((n_img, n, n, 256), dtype=self.dtype, device=x.device)
+        nxt = None if self.w1 is None else torch.empty((n_img, n, n, self.next_c), dtype=self.dtype, device=x.device)
+        check(lib().cp360_l1block_forward_first(dtype_code(self.dtype), ptr(x), ptr(self.w0), ptr(self.b0), ptr(self.w2), ptr(self.b2),
+                                                ptr(self.w3), ptr(self.b3), ptr(self.wd), ptr(out), ptr(self.w1), ptr(self.b1),
+                                                ptr(nxt), n_img, n, stream()))
         return out, nxt
 
 

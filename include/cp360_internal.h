@@ -81,6 +81,15 @@ int cp360_l1block_forward(int dtype, const void* mid, const void* w2_packed, con
                           const void* wd_frags, void* out, const void* w1_frags, const float* bias1,
                           void* out_next, int n_img, int face, void* stream);
 
+/* layer1.0 with ITS OWN conv1 inside (round 6): x [n_img, 56, 56, 64] is the block input - conv1's input and the downsample source;
+ * conv1 (1x1, 64 -> 64, + bn1 + relu, model/resnet_cubic.py:88-90) runs in place on the band's resident patch between the gather and
+ * conv2, so neither its launch nor its output tensor exists.  w0_frags = cp360_frag_pack_1x1(w1 [64, 64], order 0), bias0 f32 [64];
+ * the rest as cp360_l1block_forward's downsample form (bias3 = b3 + bd).  56x56 faces (cube 224), CP360_BF16 / CP360_F16; bit-identical
+ * to the generic conv1 launch + cp360_l1block_forward. */
+int cp360_l1block_forward_first(int dtype, const void* x, const void* w0_frags, const float* bias0, const void* w2_packed,
+                                const float* bias2, const void* w3_frags, const float* bias3, const void* wd_frags, void* out,
+                                const void* w1_frags, const float* bias1, void* out_next, int n_img, int face, void* stream);
+
 /* The LAST Bottleneck of layer1 (identity residual) chained with layer2's first conv1 (1x1, 256 -> 128 + bn1 + relu,
  * model/resnet_cubic.py:88-90 of layer2.0) - the launch that would otherwise re-read the 616 MB (64 frames) this kernel
  * writes.  Arguments as cp360_l1block_forward with residual (no x_ds); w1_frags = cp360_frag_pack_1x1(w1 [128, 256],

@@ -582,6 +582,37 @@ def test_layer1_fused_block_kernel(prec, n_img):
 
 
 @pytest.mark.parametrize('prec', ['bf16', 'fp16'])
+@pytest.mark.parametrize('n_img', [6, 30])
+def test_layer1_first_block_runs_its_own_conv1_in_the_patch(prec, n_img):
+    """csrc/l1block.hip, FIRST (round 6): layer1.0's conv1 (1x1, 64 -> 64, + bn1 + relu, resnet_cubic.py:88-90) runs in place on the band's
+    resident patch inside the block's tail kernel (cp360_l1block_forward_first).  The whole layer1 with it == the whole layer1 with conv1 as its
+    own launch, bit for bit (the halo pixels are computed again by the neighbouring bands with the same arithmetic), in both launch orders;
+    the direct pair (out, next conv1's output) likewise."""
+    from cp_360_weakly_supervised_saliency_amd.model import resnet_cubic as rc
+    dt = _TDT[prec]
+    m, sd = _load_resnet(prec)
+    x = torch.from_numpy(np.abs(hashrng.normal(4560 + n_img, (n_img, 56, 56, 64), 0.0, 1.0))).to(DEV).to(dt)
+    assert rc.FUSE_L1_FIRST
+    fused = m._layer1_fused()
+    assert fused[0].w0 is not None
+    for order in (0, 1):
+        with ops.launch_order(order):
+            out_f, mid_f = fused[0].first(x)
+            mid0 = list(m.layer1)[0]._plans()['c1'](x)
+            out_s, mid_s = fused[0](mid0, x_ds=x)
+            whole_f = m.layer1_nhwc(x)
+            rc.FUSE_L1_FIRST = False
+            try:
+                whole_s = m.layer1_nhwc(x)
+            finally:
+                rc.FUSE_L1_FIRST = True
+        torch.cuda.synchronize()
+        assert torch.equal(out_f.view(torch.int16), out_s.view(torch.int16)) and torch.equal(mid_f.view(torch.int16), mid_s.view(torch.int16))
+        assert torch.equal(whole_f.view(torch.int16), whole_s.view(torch.int16))
+    assert float(out_f.float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize('prec', ['bf16', 'fp16'])
 @pytest.mark.parametrize('face', [56, 128])
 def test_layer1_last_tail_chains_layer2_conv1(prec, face):
     """csrc/l1block.hip, l1block_wide_kernel: layer1's last Bottleneck tail also computes layer2.0's conv1 + bn1 + relu
